@@ -1,0 +1,126 @@
+"""ctypes binding of libgsplat_amd.so (the C ABI in include/gsplat_amd.h).
+
+There is no CPU fallback: if the shared library is missing, importing any of
+the operator packages raises.  PyTorch is used for device memory and streams
+only; nothing but raw device pointers and sizes crosses into the library.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsplat_amd.so")
+
+_fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+
+class GsrScene(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("P", "D", "M", "DIM", "W", "H")] + \
+               [(n, _vp) for n in ("bg", "means3D", "shs", "colors_precomp", "opacities", "scales", "rotations",
+                                   "cov3D_precomp", "reps", "viewmatrix", "projmatrix", "campos")] + \
+               [(n, C.c_float) for n in ("scale_modifier", "tanfovx", "tanfovy")] + \
+               [(n, C.c_int) for n in ("prefiltered", "antialiasing", "debug")]
+
+
+class GsrForwardOut(C.Structure):
+    _fields_ = [(n, _vp) for n in ("out_color", "out_invdepth", "radii", "accum_alpha", "gauss_sum", "gauss_count",
+                                   "last_contr_gauss", "out_depths", "out_reps")] + \
+               [("geom_buffer", _vp), ("geom_bytes", C.c_size_t), ("image_buffer", _vp), ("image_bytes", C.c_size_t)]
+
+
+class GsrBackwardIO(C.Structure):
+    _fields_ = [(n, _vp) for n in ("dL_dout_color", "dL_dout_invdepth", "dL_dout_reps", "dL_dmeans2D", "dL_dcolors",
+                                   "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations",
+                                   "dL_dreps", "work")] + [("work_bytes", C.c_size_t)]
+
+
+class GsrLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("rec", "cov3D", "tiles", "clamped", "block_sums", "total", "final_T",
+                                          "n_contrib", "ranges", "keys0", "keys1", "vals0", "vals1")] + \
+               [("sorted_buffer", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libgsplat_amd.so once.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(hipcc, --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.gsr_geom_bytes.restype = C.c_size_t
+    L.gsr_geom_bytes.argtypes = [C.c_int]
+    L.gsr_image_bytes.restype = C.c_size_t
+    L.gsr_image_bytes.argtypes = [C.c_int, C.c_int]
+    L.gsr_binning_bytes.restype = C.c_size_t
+    L.gsr_binning_bytes.argtypes = [C.c_int64]
+    L.gsr_backward_work_bytes.restype = C.c_size_t
+    L.gsr_backward_work_bytes.argtypes = [C.c_int]
+    L.gsr_sort_temp_bytes.restype = C.c_size_t
+    L.gsr_sort_temp_bytes.argtypes = [C.c_int64]
+    L.gsr_forward_stage1.restype = C.c_int
+    L.gsr_forward_stage1.argtypes = [C.POINTER(GsrScene), C.POINTER(GsrForwardOut), _vp, C.POINTER(C.c_int64)]
+    L.gsr_forward_stage2.restype = C.c_int
+    L.gsr_forward_stage2.argtypes = [C.POINTER(GsrScene), C.POINTER(GsrForwardOut), C.c_int64, _vp, C.c_size_t, _vp]
+    L.gsr_backward.restype = C.c_int
+    L.gsr_backward.argtypes = [C.POINTER(GsrScene), _vp, _vp, _vp, _vp, C.c_int64, C.POINTER(GsrBackwardIO), _vp]
+    L.gsr_mark_visible.restype = C.c_int
+    L.gsr_mark_visible.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _vp]
+    L.gsr_sort_pairs_u64_u32.restype = C.c_int
+    L.gsr_sort_pairs_u64_u32.argtypes = [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, C.c_size_t, _vp,
+                                         C.POINTER(C.c_int)]
+    L.gsr_layout.restype = C.c_int
+    L.gsr_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(GsrLayout)]
+    L.gsk_dist2_temp_bytes.restype = C.c_size_t
+    L.gsk_dist2_temp_bytes.argtypes = [C.c_int]
+    L.gsk_dist2.restype = C.c_int
+    L.gsk_dist2.argtypes = [C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]
+    L.gss_ssim_forward.restype = C.c_int
+    L.gss_ssim_forward.argtypes = [C.c_int] * 4 + [C.c_float] * 2 + [_vp] * 7
+    L.gss_ssim_backward.restype = C.c_int
+    L.gss_ssim_backward.argtypes = [C.c_int] * 4 + [C.c_float] * 2 + [_vp] * 8
+    L.gsr_status_string.restype = C.c_char_p
+    L.gsr_status_string.argtypes = [C.c_int]
+    _lib = L
+    return L
+
+
+EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backward_work_bytes",
+            "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_mark_visible", "gsr_sort_temp_bytes",
+            "gsr_sort_pairs_u64_u32", "gsr_layout", "gsk_dist2_temp_bytes", "gsk_dist2", "gss_ssim_forward",
+            "gss_ssim_backward", "gsr_status_string")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what}: {lib().gsr_status_string(rc).decode()} ({rc})")
+
+
+def ptr(t):
+    """Device pointer of a tensor, or NULL for None / empty tensors (the
+    reference passes options as empty tensors whose data_ptr() is null)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def stream_of(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def dev_f32(t, device, what):
+    """Contiguous float32 view of an input on `device` (empty tensors pass through)."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device:
+        raise RuntimeError(f"{what} must be on {device}, got {t.device}")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{what} must be float32, got {t.dtype}")
+    return t.contiguous()

@@ -1,0 +1,239 @@
+// extern "C" entry points of libgsplat_amd.so (declared in include/gsplat_amd.h).
+// Host orchestration only: argument checks, scratch-buffer carving, kernel
+// launches on the caller's stream.  Re-entrant, no globals, no allocation.
+#include "kernels.h"
+
+using namespace gs;
+
+namespace {
+
+inline int hip_status(hipError_t e) { return e == hipSuccess ? GSR_OK : GSR_ERR_HIP; }
+
+#define GSR_TRY(expr)                         \
+    do {                                      \
+        hipError_t _e = (expr);               \
+        if (_e != hipSuccess) return GSR_ERR_HIP; \
+        if (debug) {                          \
+            _e = hipStreamSynchronize(st);    \
+            if (_e != hipSuccess) return GSR_ERR_HIP; \
+        }                                     \
+    } while (0)
+
+int check_scene(const GsrScene* s) {
+    if (!s || s->P < 0 || s->W <= 0 || s->H <= 0) return GSR_ERR_ARG;
+    if (s->DIM != 0 && s->DIM != 4) return GSR_ERR_DIM;
+    if (s->P == 0) return GSR_OK;
+    if (!s->means3D || !s->opacities || !s->viewmatrix || !s->projmatrix || !s->campos || !s->bg) return GSR_ERR_ARG;
+    if ((s->shs == nullptr) == (s->colors_precomp == nullptr)) return GSR_ERR_ARG;
+    const bool sr = s->scales && s->rotations;
+    if (sr == (s->cov3D_precomp != nullptr)) return GSR_ERR_ARG;
+    if (!sr && (s->scales || s->rotations)) return GSR_ERR_ARG;
+    if (s->DIM > 0 && !s->reps) return GSR_ERR_ARG;
+    if (s->shs && (s->M <= 0 || (s->D + 1) * (s->D + 1) > s->M || s->D < 0 || s->D > 3)) return GSR_ERR_ARG;
+    if (s->W > 65535 * TILE_X || s->H > 65535 * TILE_Y) return GSR_ERR_ARG;
+    return GSR_OK;
+}
+
+int sort_end_bit(const GsrScene& s) {
+    const int gx = (s.W + TILE_X - 1) / TILE_X, gy = (s.H + TILE_Y - 1) / TILE_Y;
+    return 32 + (int)higher_msb((uint32_t)(gx * gy));
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gsr_geom_bytes(int P) { return geom_buf(nullptr, (size_t)(P > 0 ? P : 0)).bytes; }
+size_t gsr_image_bytes(int W, int H) { return image_view(nullptr, (size_t)W, (size_t)H).bytes; }
+size_t gsr_binning_bytes(int64_t R) { return bin_view(nullptr, (size_t)(R > 0 ? R : 0)).bytes; }
+size_t gsr_backward_work_bytes(int P) { return align_up((size_t)(P > 0 ? P : 1) * sizeof(GradRec), 256); }
+size_t gsr_sort_temp_bytes(int64_t n) { return sort_temp_view(nullptr, (size_t)(n > 0 ? n : 1), SORT_MAX_PASSES).bytes; }
+
+int gsr_forward_stage1(const GsrScene* s, const GsrForwardOut* o, void* stream, int64_t* num_rendered) {
+    int rc = check_scene(s);
+    if (rc != GSR_OK) return rc;
+    if (!o || !num_rendered) return GSR_ERR_ARG;
+    *num_rendered = 0;
+    if (s->P == 0) return GSR_OK;
+    if (!o->radii || !o->out_depths || !o->geom_buffer) return GSR_ERR_ARG;
+    if (o->geom_bytes < gsr_geom_bytes(s->P)) return GSR_ERR_BUFFER;
+    hipStream_t st = (hipStream_t)stream;
+    const bool debug = s->debug != 0;
+    const GeomBuf g = geom_buf(o->geom_buffer, (size_t)s->P);
+    GSR_TRY(launch_preprocess_fwd(*s, *o, g, st));
+    GSR_TRY(launch_scan_blocks(g, s->P, st));
+    uint64_t tot[2] = {0, 0};
+    if (hipMemcpyAsync(tot, g.total, sizeof(tot), hipMemcpyDeviceToHost, st) != hipSuccess) return GSR_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return GSR_ERR_HIP;
+    if (tot[1]) return GSR_ERR_OVERFLOW;
+    *num_rendered = (int64_t)tot[0];
+    return GSR_OK;
+}
+
+int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, void* binning_buffer, size_t binning_bytes,
+                       void* stream) {
+    int rc = check_scene(s);
+    if (rc != GSR_OK) return rc;
+    if (!o || R < 0) return GSR_ERR_ARG;
+    if (R >= (1ll << 30)) return GSR_ERR_OVERFLOW;
+    if (!o->out_color || !o->accum_alpha || !o->last_contr_gauss || !o->image_buffer) return GSR_ERR_ARG;
+    if (s->DIM > 0 && !o->out_reps) return GSR_ERR_ARG;
+    if (o->image_bytes < gsr_image_bytes(s->W, s->H)) return GSR_ERR_BUFFER;
+    hipStream_t st = (hipStream_t)stream;
+    const bool debug = s->debug != 0;
+    const ImageView im = image_view(o->image_buffer, (size_t)s->W, (size_t)s->H);
+    const int ntiles = ((s->W + TILE_X - 1) / TILE_X) * ((s->H + TILE_Y - 1) / TILE_Y);
+    if (s->P == 0) {
+        // nothing to blend: background everywhere
+        GSR_TRY(hipMemsetAsync(im.ranges, 0, (size_t)ntiles * sizeof(uint2), st));
+    }
+    GeomBuf g = geom_buf(s->P ? o->geom_buffer : nullptr, (size_t)s->P);
+    const uint32_t* point_list = nullptr;
+    if (s->P > 0) {
+        if (!o->gauss_sum || !o->gauss_count || !o->geom_buffer) return GSR_ERR_ARG;
+        if (R > 0) {
+            if (!binning_buffer) return GSR_ERR_ARG;
+            if (binning_bytes < gsr_binning_bytes(R)) return GSR_ERR_BUFFER;
+        }
+        BinView b = bin_view(binning_buffer, (size_t)R);
+        int res = 0;
+        if (R > 0) {
+            GSR_TRY(launch_emit_keys(*s, g, b.keys[0], b.vals[0], st));
+            GSR_TRY(launch_radix_sort(b.keys, b.vals, R, sort_end_bit(*s), b.sort_temp, st, &res));
+        }
+        GSR_TRY(launch_tile_ranges(b.keys[res], R, im.ranges, ntiles, st));
+        point_list = b.vals[res];
+    }
+    GSR_TRY(launch_render_fwd(*s, *o, g, im, point_list, st));
+    if (s->P > 0) GSR_TRY(launch_finish_gstat(g, s->P, o->gauss_sum, o->gauss_count, st));
+    if (debug && R > 0) {
+        const SortTemp t = sort_temp_view(bin_view(binning_buffer, (size_t)R).sort_temp, (size_t)R,
+                                          sort_passes_for(sort_end_bit(*s)));
+        uint32_t err = 0;
+        if (hipMemcpy(&err, t.err, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess) return GSR_ERR_HIP;
+        if (err) return GSR_ERR_SORT;
+    }
+    return GSR_OK;
+}
+
+int gsr_backward(const GsrScene* s, const int* radii, const void* geom_buffer, const void* binning_buffer,
+                 const void* image_buffer, int64_t R, const GsrBackwardIO* io, void* stream) {
+    int rc = check_scene(s);
+    if (rc != GSR_OK) return rc;
+    if (!io) return GSR_ERR_ARG;
+    if (s->P == 0) return GSR_OK;
+    if (!radii || !geom_buffer || !image_buffer || !io->dL_dout_color || !io->work) return GSR_ERR_ARG;
+    if (!io->dL_dmeans2D || !io->dL_dcolors || !io->dL_dopacity || !io->dL_dmeans3D || !io->dL_dcov3D) return GSR_ERR_ARG;
+    if (s->M > 0 && s->shs && !io->dL_dsh) return GSR_ERR_ARG;
+    if (s->scales && (!io->dL_dscales || !io->dL_drotations)) return GSR_ERR_ARG;
+    if (s->DIM > 0 && (!io->dL_dreps || !io->dL_dout_reps)) return GSR_ERR_ARG;
+    if (io->work_bytes < gsr_backward_work_bytes(s->P)) return GSR_ERR_BUFFER;
+    if (R > 0 && !binning_buffer) return GSR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool debug = s->debug != 0;
+    const GeomBuf g = geom_buf(geom_buffer, (size_t)s->P);
+    const ImageView im = image_view((void*)image_buffer, (size_t)s->W, (size_t)s->H);
+    GradRec* acc = (GradRec*)io->work;
+    GSR_TRY(hipMemsetAsync(acc, 0, (size_t)s->P * sizeof(GradRec), st));
+    if (R > 0) {
+        const BinView b = bin_view((void*)binning_buffer, (size_t)R);
+        const int res = sort_passes_for(sort_end_bit(*s)) & 1;
+        GSR_TRY(launch_render_bwd(*s, g, im, b.vals[res], *io, acc, st));
+    }
+    GSR_TRY(launch_preprocess_bwd(*s, radii, g, *io, acc, st));
+    return GSR_OK;
+}
+
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream) {
+    (void)projmatrix;
+    if (P < 0) return GSR_ERR_ARG;
+    if (P == 0) return GSR_OK;
+    if (!means3D || !viewmatrix || !present) return GSR_ERR_ARG;
+    return hip_status(launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream));
+}
+
+int gsr_sort_pairs_u64_u32(uint64_t* keys0, uint32_t* vals0, uint64_t* keys1, uint32_t* vals1, int64_t n, int end_bit,
+                           void* temp, size_t temp_bytes, void* stream, int* result_buffer) {
+    if (n < 0 || end_bit < 0 || end_bit > 64 || !result_buffer) return GSR_ERR_ARG;
+    *result_buffer = 0;
+    if (n == 0 || end_bit == 0) return GSR_OK;
+    if (n >= (1ll << 30)) return GSR_ERR_OVERFLOW;
+    if (!keys0 || !vals0 || !keys1 || !vals1 || !temp) return GSR_ERR_ARG;
+    if (temp_bytes < gsr_sort_temp_bytes(n)) return GSR_ERR_BUFFER;
+    uint64_t* k[2] = {keys0, keys1};
+    uint32_t* v[2] = {vals0, vals1};
+    return hip_status(launch_radix_sort(k, v, n, end_bit, temp, (hipStream_t)stream, result_buffer));
+}
+
+int gsr_layout(int P, int W, int H, int64_t R, GsrLayout* out) {
+    if (!out || P < 0 || W <= 0 || H <= 0 || R < 0) return GSR_ERR_ARG;
+    char* const z = (char*)4096;  // fake non-null base to turn pointers into offsets
+    const GeomBuf g = geom_buf(z, (size_t)P);
+    out->rec = (char*)g.rec - z;
+    out->cov3D = (char*)g.cov3D - z;
+    out->tiles = (char*)g.bin - z;
+    out->clamped = (char*)g.clamped - z;
+    out->block_sums = (char*)g.block_sums - z;
+    out->total = (char*)g.total - z;
+    const ImageView im = image_view(z, (size_t)W, (size_t)H);
+    out->final_T = (char*)im.final_T - z;
+    out->n_contrib = (char*)im.n_contrib - z;
+    out->ranges = (char*)im.ranges - z;
+    const BinView b = bin_view(z, (size_t)R);
+    out->keys0 = (char*)b.keys[0] - z;
+    out->keys1 = (char*)b.keys[1] - z;
+    out->vals0 = (char*)b.vals[0] - z;
+    out->vals1 = (char*)b.vals[1] - z;
+    const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
+    out->sorted_buffer = sort_passes_for(32 + (int)higher_msb((uint32_t)(gx * gy))) & 1;
+    return GSR_OK;
+}
+
+size_t gsk_dist2_temp_bytes(int P) { return knn_temp_bytes(P); }
+
+int gsk_dist2(int P, const float* points, float* mean_dists, void* temp, size_t temp_bytes, void* stream) {
+    if (P < 0) return GSR_ERR_ARG;
+    if (P == 0) return GSR_OK;
+    if (!points || !mean_dists || !temp) return GSR_ERR_ARG;
+    if (P >= (1 << 30)) return GSR_ERR_OVERFLOW;
+    if (temp_bytes < knn_temp_bytes(P)) return GSR_ERR_BUFFER;
+    return hip_status(launch_knn(P, points, mean_dists, temp, (hipStream_t)stream));
+}
+
+int gss_ssim_forward(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2,
+                     float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream) {
+    if (B < 0 || CH < 0 || H < 0 || W < 0) return GSR_ERR_ARG;
+    if ((size_t)B * CH * H * W == 0) return GSR_OK;
+    if (!img1 || !img2 || !ssim_map) return GSR_ERR_ARG;
+    if (dm_dmu1 && (!dm_dsigma1_sq || !dm_dsigma12)) return GSR_ERR_ARG;
+    return hip_status(launch_ssim_fwd(B, CH, H, W, C1, C2, img1, img2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
+                                      (hipStream_t)stream));
+}
+
+int gss_ssim_backward(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2,
+                      const float* dL_dmap, float* dL_dimg1, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                      const float* dm_dsigma12, void* stream) {
+    (void)C1;
+    (void)C2;
+    if (B < 0 || CH < 0 || H < 0 || W < 0) return GSR_ERR_ARG;
+    if ((size_t)B * CH * H * W == 0) return GSR_OK;
+    if (!img1 || !img2 || !dL_dmap || !dL_dimg1 || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12) return GSR_ERR_ARG;
+    return hip_status(launch_ssim_bwd(B, CH, H, W, img1, img2, dL_dmap, dL_dimg1, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
+                                      (hipStream_t)stream));
+}
+
+const char* gsr_status_string(int status) {
+    switch (status) {
+        case GSR_OK: return "ok";
+        case GSR_ERR_ARG: return "invalid argument";
+        case GSR_ERR_DIM: return "unsupported number of reps channels (supported: 0, 4)";
+        case GSR_ERR_OVERFLOW: return "too many Gaussian/tile instances (>= 2^30)";
+        case GSR_ERR_BUFFER: return "caller buffer too small";
+        case GSR_ERR_HIP: return "HIP runtime error";
+        case GSR_ERR_SORT: return "radix sort look-back did not complete";
+        default: return "unknown status";
+    }
+}
+
+}  // extern "C"

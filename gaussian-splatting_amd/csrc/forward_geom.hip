@@ -1,0 +1,246 @@
+// Per-Gaussian forward stages: preprocess (cull, EWA projection, conic, radius,
+// tile rectangle, SH -> RGB), the prefix sum over touched tiles, key emission
+// and tile-range detection.  Reference: cuda_rasterizer/forward.cu:151-308,
+// rasterizer_impl.cu:54-137, 326-400.
+//
+// HBM-bound stages.  One thread per Gaussian; the per-Gaussian results that the
+// blend kernels gather later are packed into one 64-byte SplatRec so that a
+// gather touches a single line half instead of five arrays.
+#include "kernels.h"
+
+namespace gs {
+
+struct PreArgs {
+    int P, D, M, DIM, W, H;
+    float mod, tanx, tany;
+    int aa;
+    const float* means3D;
+    const float* shs;
+    const float* colors_precomp;
+    const float* opacities;
+    const float* scales;
+    const float* rotations;
+    const float* cov3D_precomp;
+    const float* reps;
+    CamPtrs cam;
+    int* radii;
+    float* out_depths;
+    SplatRec* rec;
+    float* cov3D;
+    uint4* bin;
+    float2* gstat;
+    uint8_t* clamped;
+    uint32_t* block_sums;
+};
+
+struct ShGlobal {
+    const float* p;
+    __device__ __forceinline__ V3 operator()(int k) const { return v3(p[3 * k], p[3 * k + 1], p[3 * k + 2]); }
+};
+
+__global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs a) {
+    __shared__ uint32_t s_tmp[8];
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    uint32_t tiles = 0;
+    if (idx < a.P) {
+        const Cam c = load_cam(a.cam, a.W, a.H, a.tanx, a.tany, a.mod, a.D, a.M, a.aa);
+        int radius = 0;
+        uint4 bin = make_uint4(0, 0, 0, 0);
+        const V3 p = v3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+        float depth;
+        if (!near_cull(p, c.view, &depth)) {
+            float cov6[6];
+            if (a.cov3D_precomp) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) cov6[i] = a.cov3D_precomp[6 * (size_t)idx + i];
+            } else {
+                const V3 sc = v3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
+                const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[idx];
+                const V4 q = {q4.x, q4.y, q4.z, q4.w};
+                cov3d_from_scale_rot(sc, c.scale_modifier, q, cov6);
+            }
+            Splat sp;
+            if (project_splat(c, p, cov6, a.opacities[idx], depth, &sp)) {
+                V3 col;
+                if (a.colors_precomp) {
+                    col = v3(a.colors_precomp[3 * idx], a.colors_precomp[3 * idx + 1], a.colors_precomp[3 * idx + 2]);
+                } else {
+                    ShGlobal sh = {a.shs + (size_t)idx * a.M * 3};
+                    col = sh_to_rgb(c.sh_degree, p, v3(c.campos[0], c.campos[1], c.campos[2]), sh);
+                    a.clamped[idx] = (uint8_t)((col.x < 0 ? 1 : 0) | (col.y < 0 ? 2 : 0) | (col.z < 0 ? 4 : 0));
+                    col = v3(fmax_(col.x, 0.0f), fmax_(col.y, 0.0f), fmax_(col.z, 0.0f));
+                }
+                float4 rp = make_float4(0, 0, 0, 0);
+                if (a.DIM == 4) rp = reinterpret_cast<const float4*>(a.reps)[idx];
+                float4* r4 = reinterpret_cast<float4*>(a.rec + idx);
+                r4[0] = make_float4(sp.xy.x, sp.xy.y, sp.conic_opacity.x, sp.conic_opacity.y);
+                r4[1] = make_float4(sp.conic_opacity.z, sp.conic_opacity.w, col.x, col.y);
+                r4[2] = make_float4(col.z, 1 / sp.depth, rp.x, rp.y);
+                r4[3] = make_float4(rp.z, rp.w, sp.depth, 0.0f);
+                if (!a.cov3D_precomp) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) a.cov3D[6 * (size_t)idx + i] = cov6[i];
+                }
+                a.out_depths[idx] = sp.depth;
+                radius = sp.radius;
+                tiles = sp.tiles;
+                bin.x = (uint32_t)sp.rect.x0 | ((uint32_t)sp.rect.y0 << 16);
+                bin.y = (uint32_t)(sp.rect.x1 - sp.rect.x0) | ((uint32_t)(sp.rect.y1 - sp.rect.y0) << 16);
+                bin.z = f2bits(sp.depth);
+                bin.w = tiles;
+            }
+        }
+        a.radii[idx] = radius;
+        a.bin[idx] = bin;
+        a.gstat[idx] = make_float2(0.0f, 0.0f);
+    }
+    // tiles touched by this block of 256 Gaussians
+    const uint32_t ws = wave_sum_u32(tiles);
+    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) a.block_sums[blockIdx.x] = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+}
+
+// Exclusive scan of the per-block sums (one workgroup walks the array), total
+// instance count into total[0], overflow flag into total[1].
+__global__ void __launch_bounds__(256) scan_blocks_kernel(uint32_t* block_sums, int nb, uint64_t* total) {
+    __shared__ uint32_t s_tmp[8];
+    uint64_t carry = 0;
+    for (int base = 0; base < nb; base += 256) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nb ? block_sums[i] : 0;
+        uint32_t sum;
+        const uint32_t ex = block_scan_excl_256(v, s_tmp, &sum);
+        if (i < nb) block_sums[i] = (uint32_t)(carry + ex);
+        carry += sum;
+    }
+    if (threadIdx.x == 0) {
+        block_sums[nb] = (uint32_t)carry;
+        total[0] = carry;
+        total[1] = carry >= (1ull << 30) ? 1 : 0;
+    }
+}
+
+// duplicateWithKeys (rasterizer_impl.cu:70-110), balanced: the instances of a
+// block of 256 Gaussians are numbered consecutively and dealt to the threads
+// round-robin, so that both the work and the stores are uniform however large
+// individual splats are.  Output order and offsets equal the reference's.
+__global__ void __launch_bounds__(PRE_BLOCK) emit_keys_kernel(int P, int grid_x, const uint4* bin,
+                                                              const uint32_t* block_offsets, uint64_t* keys,
+                                                              uint32_t* vals) {
+    __shared__ uint32_t s_tmp[8];
+    __shared__ uint32_t s_off[PRE_BLOCK];
+    __shared__ uint4 s_bin[PRE_BLOCK];
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    const uint4 b = idx < P ? bin[idx] : make_uint4(0, 0, 0, 0);
+    uint32_t total;
+    const uint32_t ex = block_scan_excl_256(b.w, s_tmp, &total);
+    s_off[threadIdx.x] = ex;
+    s_bin[threadIdx.x] = b;
+    __syncthreads();
+    const size_t base = block_offsets[blockIdx.x];
+    for (uint32_t s = threadIdx.x; s < total; s += PRE_BLOCK) {
+        // largest g with s_off[g] <= s
+        int lo = 0;
+#pragma unroll
+        for (int step = PRE_BLOCK / 2; step >= 1; step >>= 1)
+            if (s_off[lo + step] <= s) lo += step;
+        const uint4 gb = s_bin[lo];
+        const uint32_t q = s - s_off[lo];
+        const uint32_t w = gb.y & 0xffffu;
+        const uint32_t ty = q / w;
+        const uint32_t tx = q - ty * w;
+        const uint32_t tile = ((gb.x >> 16) + ty) * (uint32_t)grid_x + (gb.x & 0xffffu) + tx;
+        keys[base + s] = ((uint64_t)tile << 32) | gb.z;
+        vals[base + s] = (uint32_t)(blockIdx.x * PRE_BLOCK + lo);
+    }
+}
+
+// rasterizer_impl.cu:115-137
+__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint64_t* keys, int64_t R, uint2* ranges) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R) return;
+    const uint32_t cur = (uint32_t)(keys[i] >> 32);
+    if (i == 0) {
+        ranges[cur].x = 0;
+    } else {
+        const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
+        if (cur != prev) {
+            ranges[prev].y = (uint32_t)i;
+            ranges[cur].x = (uint32_t)i;
+        }
+    }
+    if (i == R - 1) ranges[cur].y = (uint32_t)R;
+}
+
+__global__ void __launch_bounds__(256) finish_gstat_kernel(int P, const float2* gstat, float* gauss_sum,
+                                                           int* gauss_count) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float2 v = gstat[i];
+    gauss_sum[i] = v.x;
+    gauss_count[i] = (int)v.y;
+}
+
+// rasterizer_impl.cu:54-66
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* means3D, const float* view,
+                                                           uint8_t* present) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float vm[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) vm[k] = view[k];
+    float d;
+    present[i] = near_cull(v3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]), vm, &d) ? 0 : 1;
+}
+
+// ------------------------------------------------------------------ launchers
+
+hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, const GeomBuf& g, hipStream_t st) {
+    PreArgs a;
+    a.P = s.P; a.D = s.D; a.M = s.M; a.DIM = s.DIM; a.W = s.W; a.H = s.H;
+    a.mod = s.scale_modifier; a.tanx = s.tanfovx; a.tany = s.tanfovy; a.aa = s.antialiasing;
+    a.means3D = s.means3D; a.shs = s.shs; a.colors_precomp = s.colors_precomp; a.opacities = s.opacities;
+    a.scales = s.scales; a.rotations = s.rotations; a.cov3D_precomp = s.cov3D_precomp; a.reps = s.reps;
+    a.cam.view = s.viewmatrix; a.cam.proj = s.projmatrix; a.cam.campos = s.campos;
+    a.radii = o.radii; a.out_depths = o.out_depths;
+    a.rec = g.rec; a.cov3D = g.cov3D; a.bin = g.bin; a.gstat = g.gstat; a.clamped = g.clamped;
+    a.block_sums = g.block_sums;
+    const int nb = (s.P + PRE_BLOCK - 1) / PRE_BLOCK;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_blocks(const GeomBuf& g, int P, hipStream_t st) {
+    const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, g.block_sums, nb, g.total);
+    return hipGetLastError();
+}
+
+hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, uint64_t* keys, uint32_t* vals, hipStream_t st) {
+    const int nb = (s.P + PRE_BLOCK - 1) / PRE_BLOCK;
+    const int grid_x = (s.W + TILE_X - 1) / TILE_X;
+    hipLaunchKernelGGL(emit_keys_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, s.P, grid_x, g.bin, g.block_sums, keys,
+                       vals);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_ranges(const uint64_t* keys, int64_t R, uint2* ranges, int ntiles, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), st);
+    if (e != hipSuccess || R <= 0) return e;
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, keys, R, ranges);
+    return hipGetLastError();
+}
+
+hipError_t launch_finish_gstat(const GeomBuf& g, int P, float* gauss_sum, int* gauss_count, hipStream_t st) {
+    hipLaunchKernelGGL(finish_gstat_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, g.gstat, gauss_sum,
+                       gauss_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st) {
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, means3D, view, present);
+    return hipGetLastError();
+}
+
+}  // namespace gs

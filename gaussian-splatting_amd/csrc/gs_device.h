@@ -1,0 +1,227 @@
+// Device-side helpers for gfx950 (wave64): DPP reductions, scans, and the
+// layout of the three scratch buffers that travel from forward to backward.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gs_math.h"
+
+namespace gs {
+
+constexpr int WAVE = 64;
+
+// ------------------------------------------------------------------ wave ops
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+
+// Sum over the 64 lanes; result valid in lane 63 only.
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v += dpp_f<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_f<0x140, 0xf>(v);  // row_mirror
+    v += dpp_f<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_f<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// Sum over the 64 lanes, returned wave-uniform (SGPR).
+__device__ __forceinline__ float wave_sum(float v) {
+    v = wave_sum_lane63(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    v += dpp_u<0xB1, 0xf>(v);
+    v += dpp_u<0x4E, 0xf>(v);
+    v += dpp_u<0x141, 0xf>(v);
+    v += dpp_u<0x140, 0xf>(v);
+    v += dpp_u<0x142, 0xa>(v);
+    v += dpp_u<0x143, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Inclusive prefix sum over the 64 lanes (row_shr scan, then row broadcasts).
+__device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t v) {
+    v += dpp_u<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_u<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_u<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_u<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_u<0x142, 0xa>(v);  // row_bcast:15
+    v += dpp_u<0x143, 0xc>(v);  // row_bcast:31
+    return v;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0)); }
+
+// Block-wide exclusive scan of one u32 per thread, 256 threads.  `tmp` holds
+// at least 5 words of LDS.  Returns the exclusive prefix; *total gets the sum.
+__device__ __forceinline__ uint32_t block_scan_excl_256(uint32_t v, uint32_t* tmp, uint32_t* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t incl = wave_scan_incl_u32(v);
+    if (lane == 63) tmp[w] = incl;
+    __syncthreads();
+    uint32_t base = 0, sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t t = tmp[i];
+        if (i < w) base += t;
+        sum += t;
+    }
+    __syncthreads();
+    *total = sum;
+    return base + incl - v;
+}
+
+// ------------------------------------------------------------------ buffers
+// One Gaussian's screen-space record, written by the forward preprocess and
+// gathered (one 64-byte line half) by both render kernels.
+struct __attribute__((aligned(16))) SplatRec {
+    float x, y, cx, cy;        // pixel centre, conic.x, conic.y
+    float cz, opacity, r, g;   // conic.z, opacity (x antialiasing factor), colour
+    float b, invdepth, rep0, rep1;
+    float rep2, rep3, depth, pad;
+};
+static_assert(sizeof(SplatRec) == 64, "SplatRec must be 64 bytes");
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+constexpr int PRE_BLOCK = 256;  // Gaussians per preprocess / key-emit workgroup
+
+struct GeomView {
+    SplatRec* rec;          // [P]
+    float* cov3D;           // [P,6]
+    uint32_t* tiles;        // [P]
+    uint8_t* clamped;       // [P] bit c set: channel c was clamped at zero
+    uint32_t* block_sums;   // [nblocks] tiles per 256-Gaussian block, then exclusive offsets
+    uint64_t* total;        // [2] number of instances; [1] = overflow flag
+    size_t bytes;
+};
+
+inline GeomView geom_view(void* base, size_t P) {
+    GeomView v;
+    char* p = (char*)base;
+    const size_t nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+    size_t off = 0;
+    auto take = [&](size_t n) { char* q = p ? p + off : nullptr; off = align_up(off + n, 256); return q; };
+    v.rec = (SplatRec*)take(P * sizeof(SplatRec));
+    v.cov3D = (float*)take(P * 6 * sizeof(float));
+    v.tiles = (uint32_t*)take(P * sizeof(uint32_t));
+    v.clamped = (uint8_t*)take(P);
+    v.block_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));
+    v.total = (uint64_t*)take(2 * sizeof(uint64_t));
+    v.bytes = off;
+    return v;
+}
+
+struct ImageView {
+    float* final_T;       // [H*W]
+    uint32_t* n_contrib;  // [H*W]
+    uint2* ranges;        // [tiles]
+    size_t bytes;
+};
+
+inline ImageView image_view(void* base, size_t W, size_t H) {
+    ImageView v;
+    char* p = (char*)base;
+    const size_t N = W * H;
+    const size_t ntiles = ((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
+    size_t off = 0;
+    auto take = [&](size_t n) { char* q = p ? p + off : nullptr; off = align_up(off + n, 256); return q; };
+    v.final_T = (float*)take(N * sizeof(float));
+    v.n_contrib = (uint32_t*)take(N * sizeof(uint32_t));
+    v.ranges = (uint2*)take(ntiles * sizeof(uint2));
+    v.bytes = off;
+    return v;
+}
+
+constexpr int SORT_TILE = 4096;   // keys per onesweep workgroup
+constexpr int SORT_MAX_PASSES = 8;
+
+struct SortTemp {
+    uint32_t* ghist;    // [SORT_MAX_PASSES][256] digit histograms, then exclusive bases
+    uint32_t* ticket;   // [SORT_MAX_PASSES]
+    uint32_t* err;      // [1]
+    uint32_t* status;   // [passes][tiles][256]
+    size_t zero_bytes;  // bytes from ghist that must be zero before a sort
+    size_t bytes;
+};
+
+inline SortTemp sort_temp_view(void* base, size_t n, int passes) {
+    SortTemp v;
+    char* p = (char*)base;
+    const size_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
+    size_t off = 0;
+    auto take = [&](size_t nb) { char* q = p ? p + off : nullptr; off = align_up(off + nb, 256); return q; };
+    v.ghist = (uint32_t*)take(SORT_MAX_PASSES * 256 * sizeof(uint32_t));
+    v.ticket = (uint32_t*)take(SORT_MAX_PASSES * sizeof(uint32_t));
+    v.err = (uint32_t*)take(sizeof(uint32_t));
+    v.status = (uint32_t*)take((size_t)passes * tiles * 256 * sizeof(uint32_t));
+    v.zero_bytes = off;
+    v.bytes = off;
+    return v;
+}
+
+struct BinView {
+    uint64_t* keys[2];
+    uint32_t* vals[2];
+    void* sort_temp;
+    size_t bytes;
+};
+
+inline BinView bin_view(void* base, size_t R) {
+    BinView v;
+    char* p = (char*)base;
+    size_t off = 0;
+    auto take = [&](size_t n) { char* q = p ? p + off : nullptr; off = align_up(off + n, 256); return q; };
+    const size_t n = R ? R : 1;
+    v.keys[0] = (uint64_t*)take(n * sizeof(uint64_t));
+    v.keys[1] = (uint64_t*)take(n * sizeof(uint64_t));
+    v.vals[0] = (uint32_t*)take(n * sizeof(uint32_t));
+    v.vals[1] = (uint32_t*)take(n * sizeof(uint32_t));
+    v.sort_temp = take(sort_temp_view(nullptr, n, SORT_MAX_PASSES).bytes);
+    v.bytes = off;
+    return v;
+}
+
+// Pointers to camera constants that live in device memory (the caller's
+// tensors); kernels read them through uniform (scalar) loads.
+struct CamPtrs {
+    const float* view;
+    const float* proj;
+    const float* campos;
+};
+
+__device__ __forceinline__ Cam load_cam(const CamPtrs& cp, int W, int H, float tanx, float tany, float mod, int D, int M,
+                                        int aa) {
+    Cam c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        c.view[i] = cp.view[i];
+        c.proj[i] = cp.proj[i];
+    }
+    c.campos[0] = cp.campos[0];
+    c.campos[1] = cp.campos[1];
+    c.campos[2] = cp.campos[2];
+    c.W = W;
+    c.H = H;
+    c.tanfovx = tanx;
+    c.tanfovy = tany;
+    c.scale_modifier = mod;
+    c.sh_degree = D;
+    c.sh_coeffs = M;
+    c.antialiasing = aa;
+    cam_finish(&c);
+    return c;
+}
+
+}  // namespace gs

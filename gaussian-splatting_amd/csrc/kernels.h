@@ -1,0 +1,80 @@
+// Host-callable launchers of the HIP kernels (internal to libgsplat_amd.so).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gsplat_amd.h"
+#include "gs_device.h"
+
+namespace gs {
+
+// Geometry buffer with the extra per-Gaussian arrays this implementation keeps.
+struct GeomBuf {
+    SplatRec* rec;        // [P]
+    float* cov3D;         // [P,6]
+    uint4* bin;           // [P] {x0 | y0<<16, w | h<<16, depth bits, tiles}
+    float2* gstat;        // [P] (sum of T, hit count as float), accumulated by the forward blend
+    uint8_t* clamped;     // [P]
+    uint32_t* block_sums; // [nblocks+1]
+    uint64_t* total;      // [2]
+    size_t bytes;
+};
+
+inline GeomBuf geom_buf(const void* base, size_t P) {
+    GeomBuf v;
+    char* p = (char*)base;
+    const size_t nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+    size_t off = 0;
+    auto take = [&](size_t n) { char* q = p ? p + off : nullptr; off = align_up(off + n, 256); return q; };
+    v.rec = (SplatRec*)take(P * sizeof(SplatRec));
+    v.cov3D = (float*)take(P * 6 * sizeof(float));
+    v.bin = (uint4*)take(P * sizeof(uint4));
+    v.gstat = (float2*)take(P * sizeof(float2));
+    v.clamped = (uint8_t*)take(P);
+    v.block_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));
+    v.total = (uint64_t*)take(2 * sizeof(uint64_t));
+    v.bytes = off;
+    return v;
+}
+
+// Per-Gaussian gradient accumulator filled by the backward blend (atomics,
+// one 64-byte line half per Gaussian) and consumed by the backward preprocess.
+struct __attribute__((aligned(16))) GradRec {
+    float mean2d_x, mean2d_y, conic_x, conic_y;
+    float conic_w, opacity, col_r, col_g;
+    float col_b, invdepth, rep0, rep1;
+    float rep2, rep3, pad0, pad1;
+};
+static_assert(sizeof(GradRec) == 64, "GradRec must be 64 bytes");
+
+int sort_passes_for(int end_bit);
+
+hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, const GeomBuf& g, hipStream_t st);
+hipError_t launch_scan_blocks(const GeomBuf& g, int P, hipStream_t st);
+hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, uint64_t* keys, uint32_t* vals, hipStream_t st);
+hipError_t launch_tile_ranges(const uint64_t* keys, int64_t R, uint2* ranges, int ntiles, hipStream_t st);
+hipError_t launch_finish_gstat(const GeomBuf& g, int P, float* gauss_sum, int* gauss_count, hipStream_t st);
+hipError_t launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);
+
+// Returns the index (0/1) of the buffer pair that holds the sorted result.
+hipError_t launch_radix_sort(uint64_t* keys[2], uint32_t* vals[2], int64_t n, int end_bit, void* temp, hipStream_t st,
+                             int* result_buffer);
+
+hipError_t launch_render_fwd(const GsrScene& s, const GsrForwardOut& o, const GeomBuf& g, const ImageView& im,
+                             const uint32_t* point_list, hipStream_t st);
+hipError_t launch_render_bwd(const GsrScene& s, const GeomBuf& g, const ImageView& im, const uint32_t* point_list,
+                             const GsrBackwardIO& io, GradRec* acc, hipStream_t st);
+hipError_t launch_preprocess_bwd(const GsrScene& s, const int* radii, const GeomBuf& g, const GsrBackwardIO& io,
+                                 const GradRec* acc, hipStream_t st);
+
+hipError_t launch_knn(int P, const float* points, float* out, void* temp, hipStream_t st);
+size_t knn_temp_bytes(int P);
+
+hipError_t launch_ssim_fwd(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2,
+                           float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, hipStream_t st);
+hipError_t launch_ssim_bwd(int B, int CH, int H, int W, const float* img1, const float* img2, const float* dL_dmap,
+                           float* dL_dimg1, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
+                           hipStream_t st);
+
+}  // namespace gs

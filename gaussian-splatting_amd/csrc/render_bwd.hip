@@ -1,0 +1,257 @@
+// Backward of the alpha compositing.  Reference: cuda_rasterizer/backward.cu:474-686.
+//
+// Same tiling as the forward (16x16 tile, 4 wave64 quadrants); the tile's list
+// is walked back to front starting at the last instance any pixel of the tile
+// actually blended.  The reference issues up to 14 global float atomics per
+// (pixel, Gaussian) pair; here each gradient component is first summed over the
+// wave's 64 pixels with DPP adds, then over the four waves in LDS, and leaves
+// the workgroup once per (tile, instance) as a 64-byte GradRec update: 16 lanes
+// add to 16 consecutive floats, so one wave instruction carries four complete
+// line-half atomics instead of 64 scattered ones.
+#include "kernels.h"
+
+namespace gs {
+
+struct RenderBwdArgs {
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const SplatRec* rec;
+    const float* bg;
+    int W, H, grid_x, ntiles;
+    const float* final_T;
+    const uint32_t* n_contrib;
+    const float* dL_dpix;
+    const float* dL_dinvdepth;
+    const float* dL_dreps;
+    float* acc;  // GradRec[P] viewed as floats
+};
+
+__device__ __forceinline__ int xcd_remap_b(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+template <int DIM, bool INVD>
+__global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArgs a) {
+    __shared__ float4 s_q0[TILE_PIX];
+    __shared__ float4 s_q1[TILE_PIX];
+    __shared__ float4 s_q2[TILE_PIX];
+    __shared__ float4 s_q3[TILE_PIX];
+    __shared__ uint32_t s_id[TILE_PIX];
+    __shared__ float s_acc[TILE_PIX][16];
+    __shared__ uint32_t s_max[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = xcd_remap_b(blockIdx.x, a.ntiles);
+    const int tx = tile % a.grid_x, ty = tile / a.grid_x;
+    const int px = tx * TILE_X + (w & 1) * 8 + (lane & 7);
+    const int py = ty * TILE_Y + (w >> 1) * 8 + (lane >> 3);
+    const bool inside = px < a.W && py < a.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint2 range = a.ranges[tile];
+    const size_t pid = (size_t)py * a.W + px;
+    const size_t HW = (size_t)a.H * a.W;
+
+    const float T_final = inside ? a.final_T[pid] : 0.f;
+    float T = T_final;
+    const uint32_t last_contributor = inside ? a.n_contrib[pid] : 0u;
+
+    float dpix0 = 0.f, dpix1 = 0.f, dpix2 = 0.f, dinvd = 0.f;
+    float drep[DIM > 0 ? DIM : 1];
+#pragma unroll
+    for (int i = 0; i < (DIM > 0 ? DIM : 1); ++i) drep[i] = 0.f;
+    if (inside) {
+        dpix0 = a.dL_dpix[pid];
+        dpix1 = a.dL_dpix[HW + pid];
+        dpix2 = a.dL_dpix[2 * HW + pid];
+        if (DIM == 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) drep[i] = a.dL_dreps[i * HW + pid];
+        }
+        if (INVD) dinvd = a.dL_dinvdepth[pid];
+    }
+    float bg_dot_dpixel = 0;
+    bg_dot_dpixel += a.bg[0] * dpix0;
+    bg_dot_dpixel += a.bg[1] * dpix1;
+    bg_dot_dpixel += a.bg[2] * dpix2;
+
+    float accum_rec0 = 0.f, accum_rec1 = 0.f, accum_rec2 = 0.f, accum_invd = 0.f;
+    float last_c0 = 0.f, last_c1 = 0.f, last_c2 = 0.f, last_invd = 0.f, last_alpha = 0.f;
+    float accum_rep[DIM > 0 ? DIM : 1], last_rep[DIM > 0 ? DIM : 1];
+#pragma unroll
+    for (int i = 0; i < (DIM > 0 ? DIM : 1); ++i) accum_rep[i] = last_rep[i] = 0.f;
+
+    const float ddelx_dx = 0.5f * a.W;
+    const float ddely_dy = 0.5f * a.H;
+
+    // number of list entries any pixel of this tile needs
+    {
+        uint32_t m = last_contributor;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+        if (lane == 0) s_max[w] = m;
+    }
+    __syncthreads();
+    const int max_last = (int)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+
+    for (int base = 0; base < max_last; base += TILE_PIX) {
+        __syncthreads();
+        const int nb = min(TILE_PIX, max_last - base);
+        if (tid < nb) {
+            const uint32_t id = a.point_list[range.x + (uint32_t)(max_last - 1 - base - tid)];
+            const float4* r4 = reinterpret_cast<const float4*>(a.rec + id);
+            s_id[tid] = id;
+            s_q0[tid] = r4[0];
+            s_q1[tid] = r4[1];
+            s_q2[tid] = r4[2];
+            if (DIM > 2) s_q3[tid] = r4[3];
+        }
+        {
+            float4* z = reinterpret_cast<float4*>(&s_acc[tid][0]);
+            z[0] = z[1] = z[2] = z[3] = make_float4(0, 0, 0, 0);
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int j = 0; j < nb; ++j) {
+            const uint32_t contributor = (uint32_t)(max_last - 1 - base - j);
+            const float4 q0 = s_q0[j];
+            const float4 q1 = s_q1[j];
+            const V2 xy = {q0.x, q0.y};
+            const V4 co = {q0.z, q0.w, q1.x, q1.y};
+            float dx, dy;
+            const float power = splat_power(xy, pxf, pyf, co, &dx, &dy);
+            bool valid = inside && contributor < last_contributor && !(power > 0.0f);
+            if (__ballot(valid) == 0) continue;
+            const float G = gs_expf(power);
+            const float alpha = fmin_(GS_ALPHA_MAX, co.w * G);
+            valid = valid && !(alpha < GS_ALPHA_MIN);
+            if (__ballot(valid) == 0) continue;
+
+            const float4 q2 = s_q2[j];
+            float4 q3 = make_float4(0, 0, 0, 0);
+            if (DIM == 4) q3 = s_q3[j];
+
+            float g_mx = 0.f, g_my = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_op = 0.f;
+            float g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, g_id = 0.f;
+            float g_rep[DIM > 0 ? DIM : 1];
+#pragma unroll
+            for (int i = 0; i < (DIM > 0 ? DIM : 1); ++i) g_rep[i] = 0.f;
+
+            if (valid) {
+                T = T / (1.f - alpha);
+                const float dchannel_dcolor = alpha * T;
+                float dL_dalpha = 0.0f;
+                {
+                    accum_rec0 = last_alpha * last_c0 + (1.f - last_alpha) * accum_rec0;
+                    last_c0 = q1.z;
+                    dL_dalpha += (q1.z - accum_rec0) * dpix0;
+                    g_c0 = dchannel_dcolor * dpix0;
+                    accum_rec1 = last_alpha * last_c1 + (1.f - last_alpha) * accum_rec1;
+                    last_c1 = q1.w;
+                    dL_dalpha += (q1.w - accum_rec1) * dpix1;
+                    g_c1 = dchannel_dcolor * dpix1;
+                    accum_rec2 = last_alpha * last_c2 + (1.f - last_alpha) * accum_rec2;
+                    last_c2 = q2.x;
+                    dL_dalpha += (q2.x - accum_rec2) * dpix2;
+                    g_c2 = dchannel_dcolor * dpix2;
+                }
+                if (DIM == 4) {
+                    const float rv[4] = {q2.z, q2.w, q3.x, q3.y};
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) {
+                        accum_rep[ch] = last_alpha * last_rep[ch] + (1.f - last_alpha) * accum_rep[ch];
+                        last_rep[ch] = rv[ch];
+                        dL_dalpha += (rv[ch] - accum_rep[ch]) * drep[ch];
+                        g_rep[ch] = dchannel_dcolor * drep[ch];
+                    }
+                }
+                if (INVD) {
+                    const float invd = q2.y;
+                    accum_invd = last_alpha * last_invd + (1.f - last_alpha) * accum_invd;
+                    last_invd = invd;
+                    dL_dalpha += (invd - accum_invd) * dinvd;
+                    g_id = dchannel_dcolor * dinvd;
+                }
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+
+                g_op = G * dL_dalpha;
+                const float dL_dG = co.w * dL_dalpha;
+                const float gdx = G * dx;
+                const float gdy = G * dy;
+                const float dG_ddelx = -gdx * co.x - gdy * co.y;
+                const float dG_ddely = -gdy * co.z - gdx * co.y;
+                g_mx = dL_dG * dG_ddelx * ddelx_dx;
+                g_my = dL_dG * dG_ddely * ddely_dy;
+                g_cx = -0.5f * gdx * dx * dL_dG;
+                g_cy = -0.5f * gdx * dy * dL_dG;
+                g_cw = -0.5f * gdy * dy * dL_dG;
+            }
+
+            float* dst = &s_acc[j][0];
+            float r;
+#define GS_RED(slot, v)                     \
+    r = wave_sum_lane63(v);                 \
+    if (lane == 63) atomicAdd(dst + slot, r);
+            GS_RED(0, g_mx)
+            GS_RED(1, g_my)
+            GS_RED(2, g_cx)
+            GS_RED(3, g_cy)
+            GS_RED(4, g_cw)
+            GS_RED(5, g_op)
+            GS_RED(6, g_c0)
+            GS_RED(7, g_c1)
+            GS_RED(8, g_c2)
+            if (INVD) { GS_RED(9, g_id) }
+            if (DIM == 4) {
+                GS_RED(10, g_rep[0])
+                GS_RED(11, g_rep[1])
+                GS_RED(12, g_rep[2])
+                GS_RED(13, g_rep[3])
+            }
+#undef GS_RED
+        }
+        __syncthreads();
+        // 16 lanes per instance: one 64-byte GradRec update
+#pragma unroll 1
+        for (int h = 0; h < 16; ++h) {
+            const int j = (tid >> 4) + 16 * h;
+            if (j >= nb) break;
+            const float v = s_acc[j][tid & 15];
+            if (v != 0.0f) atomicAdd(a.acc + (size_t)s_id[j] * 16 + (tid & 15), v);
+        }
+    }
+}
+
+hipError_t launch_render_bwd(const GsrScene& s, const GeomBuf& g, const ImageView& im, const uint32_t* point_list,
+                             const GsrBackwardIO& io, GradRec* acc, hipStream_t st) {
+    RenderBwdArgs a;
+    a.ranges = im.ranges;
+    a.point_list = point_list;
+    a.rec = g.rec;
+    a.bg = s.bg;
+    a.W = s.W;
+    a.H = s.H;
+    a.grid_x = (s.W + TILE_X - 1) / TILE_X;
+    a.ntiles = a.grid_x * ((s.H + TILE_Y - 1) / TILE_Y);
+    a.final_T = im.final_T;
+    a.n_contrib = im.n_contrib;
+    a.dL_dpix = io.dL_dout_color;
+    a.dL_dinvdepth = io.dL_dout_invdepth;
+    a.dL_dreps = io.dL_dout_reps;
+    a.acc = reinterpret_cast<float*>(acc);
+    const dim3 grid(a.ntiles), block(TILE_PIX);
+    const bool invd = io.dL_dout_invdepth != nullptr;
+    if (s.DIM == 4) {
+        if (invd) hipLaunchKernelGGL((render_bwd_kernel<4, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((render_bwd_kernel<4, false>), grid, block, 0, st, a);
+    } else {
+        if (invd) hipLaunchKernelGGL((render_bwd_kernel<0, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((render_bwd_kernel<0, false>), grid, block, 0, st, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace gs

@@ -1,0 +1,209 @@
+// Forward alpha compositing, one 16x16 tile per 256-thread workgroup (4
+// wave64 wavefronts, each owning an 8x8 pixel quadrant).  Reference:
+// cuda_rasterizer/forward.cu:313-490.
+//
+// Per round the workgroup gathers the 64-byte SplatRec of 256 instances into
+// LDS; every wave then walks the batch with wave-uniform (broadcast) LDS
+// reads.  A wave whose 64 pixels are all saturated stops computing (ballot);
+// the workgroup stops when its four waves have.  The per-Gaussian statistics
+// of the fork (sum of transmittance and hit count, forward.cu:431-432) are
+// reduced over the wave with DPP adds, over the four waves through LDS, and
+// leave the workgroup as one pair of adjacent float atomics per instance.
+#include "kernels.h"
+
+namespace gs {
+
+struct RenderFwdArgs {
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const SplatRec* rec;
+    float2* gstat;
+    const float* bg;
+    int W, H, grid_x, ntiles;
+    float* final_T;
+    uint32_t* n_contrib;
+    float* out_color;
+    float* out_invdepth;
+    float* accum_alpha;
+    int* last_contr;
+    float* out_reps;
+};
+
+// Consecutive tile ids land on one XCD (workgroups are dealt round-robin over
+// the 8 XCDs), so neighbouring tiles share that XCD's L2 for SplatRec gathers.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+template <int DIM, bool INVD>
+__global__ void __launch_bounds__(TILE_PIX) render_fwd_kernel(const RenderFwdArgs a) {
+    __shared__ float4 s_q0[TILE_PIX];  // x, y, conic.x, conic.y
+    __shared__ float4 s_q1[TILE_PIX];  // conic.z, opacity, r, g
+    __shared__ float4 s_q2[TILE_PIX];  // b, 1/depth, rep0, rep1
+    __shared__ float4 s_q3[TILE_PIX];  // rep2, rep3, depth, -
+    __shared__ uint32_t s_id[TILE_PIX];
+    __shared__ float s_gsum[4][TILE_PIX];
+    __shared__ float s_gcnt[4][TILE_PIX];
+    __shared__ int s_wdone[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = xcd_remap(blockIdx.x, a.ntiles);
+    const int tx = tile % a.grid_x, ty = tile / a.grid_x;
+    const int px = tx * TILE_X + (w & 1) * 8 + (lane & 7);
+    const int py = ty * TILE_Y + (w >> 1) * 8 + (lane >> 3);
+    const bool inside = px < a.W && py < a.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint2 range = a.ranges[tile];
+    const int total = (int)(range.y - range.x);
+
+    bool done = !inside;
+    float T = 1.0f;
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, invd = 0.f;
+    float Re[DIM > 0 ? DIM : 1];
+#pragma unroll
+    for (int i = 0; i < (DIM > 0 ? DIM : 1); ++i) Re[i] = 0.f;
+    uint32_t last = 0;
+    int last_g = -1;
+
+    if (tid < 4) s_wdone[tid] = 0;
+
+    for (int base = 0; base < total; base += TILE_PIX) {
+        __syncthreads();
+        if (s_wdone[0] & s_wdone[1] & s_wdone[2] & s_wdone[3]) break;
+        const int nb = min(TILE_PIX, total - base);
+        if (tid < nb) {
+            const uint32_t id = a.point_list[range.x + base + tid];
+            const float4* r4 = reinterpret_cast<const float4*>(a.rec + id);
+            s_id[tid] = id;
+            s_q0[tid] = r4[0];
+            s_q1[tid] = r4[1];
+            s_q2[tid] = r4[2];
+            if (DIM > 2) s_q3[tid] = r4[3];
+        }
+        __syncthreads();
+
+        bool wave_done = __ballot(!done) == 0;
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            float acc_s = 0.f, acc_c = 0.f;
+            const int jend = min(64, nb - k * 64);
+            if (!wave_done) {
+#pragma unroll 1
+                for (int jj = 0; jj < jend; ++jj) {
+                    const int j = k * 64 + jj;
+                    const float4 q0 = s_q0[j];
+                    const float4 q1 = s_q1[j];
+                    const V2 xy = {q0.x, q0.y};
+                    const V4 co = {q0.z, q0.w, q1.x, q1.y};
+                    float dx, dy;
+                    const float power = splat_power(xy, pxf, pyf, co, &dx, &dy);
+                    const bool hit = !done && !(power > 0.0f);
+                    const uint64_t hm = __ballot(hit);
+                    if (hm == 0) continue;
+                    const float S = wave_sum(hit ? T : 0.0f);
+                    const float cnt = (float)__popcll(hm);
+                    acc_s = (lane == jj) ? S : acc_s;
+                    acc_c = (lane == jj) ? cnt : acc_c;
+
+                    const float alpha = fmin_(GS_ALPHA_MAX, co.w * gs_expf(power));
+                    const bool pass = hit && !(alpha < GS_ALPHA_MIN);
+                    const float test_T = T * (1 - alpha);
+                    const bool term = pass && (test_T < GS_T_MIN);
+                    done = done || term;
+                    const bool blend = pass && !term;
+                    if (__ballot(blend)) {
+                        const float4 q2 = s_q2[j];
+                        if (blend) {
+                            C0 += q1.z * alpha * T;
+                            C1 += q1.w * alpha * T;
+                            C2 += q2.x * alpha * T;
+                            if (INVD) invd += q2.y * alpha * T;
+                            if (DIM == 4) {
+                                const float4 q3 = s_q3[j];
+                                Re[0] += q2.z * alpha * T;
+                                Re[1] += q2.w * alpha * T;
+                                Re[2] += q3.x * alpha * T;
+                                Re[3] += q3.y * alpha * T;
+                            }
+                            T = test_T;
+                            last = (uint32_t)(base + j + 1);
+                            last_g = (int)s_id[j];
+                        }
+                    }
+                    if (__ballot(!done) == 0) {
+                        wave_done = true;
+                        break;
+                    }
+                }
+            }
+            s_gsum[w][k * 64 + lane] = acc_s;
+            s_gcnt[w][k * 64 + lane] = acc_c;
+        }
+        if (lane == 0) s_wdone[w] = wave_done ? 1 : 0;
+        __syncthreads();
+        // thread t: component (t & 1) of instance (t >> 1) + 128 h
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = (tid >> 1) + 128 * h;
+            if (j < nb) {
+                const float c = s_gcnt[0][j] + s_gcnt[1][j] + s_gcnt[2][j] + s_gcnt[3][j];
+                if (c > 0.0f) {
+                    const float s = s_gsum[0][j] + s_gsum[1][j] + s_gsum[2][j] + s_gsum[3][j];
+                    float* dst = reinterpret_cast<float*>(a.gstat + s_id[j]) + (tid & 1);
+                    atomicAdd(dst, (tid & 1) ? c : s);
+                }
+            }
+        }
+    }
+
+    if (inside) {
+        const size_t pid = (size_t)py * a.W + px;
+        const size_t HW = (size_t)a.H * a.W;
+        a.final_T[pid] = T;
+        a.accum_alpha[pid] = T;
+        a.n_contrib[pid] = last;
+        a.last_contr[pid] = last_g;
+        a.out_color[pid] = C0 + T * a.bg[0];
+        a.out_color[HW + pid] = C1 + T * a.bg[1];
+        a.out_color[2 * HW + pid] = C2 + T * a.bg[2];
+        if (DIM == 4) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) a.out_reps[ch * HW + pid] = Re[ch];
+        }
+        if (INVD) a.out_invdepth[pid] = invd;
+    }
+}
+
+hipError_t launch_render_fwd(const GsrScene& s, const GsrForwardOut& o, const GeomBuf& g, const ImageView& im,
+                             const uint32_t* point_list, hipStream_t st) {
+    RenderFwdArgs a;
+    a.ranges = im.ranges;
+    a.point_list = point_list;
+    a.rec = g.rec;
+    a.gstat = g.gstat;
+    a.bg = s.bg;
+    a.W = s.W;
+    a.H = s.H;
+    a.grid_x = (s.W + TILE_X - 1) / TILE_X;
+    a.ntiles = a.grid_x * ((s.H + TILE_Y - 1) / TILE_Y);
+    a.final_T = im.final_T;
+    a.n_contrib = im.n_contrib;
+    a.out_color = o.out_color;
+    a.out_invdepth = o.out_invdepth;
+    a.accum_alpha = o.accum_alpha;
+    a.last_contr = o.last_contr_gauss;
+    a.out_reps = o.out_reps;
+    const dim3 grid(a.ntiles), block(TILE_PIX);
+    const bool invd = o.out_invdepth != nullptr;
+    if (s.DIM == 4) {
+        if (invd) hipLaunchKernelGGL((render_fwd_kernel<4, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((render_fwd_kernel<4, false>), grid, block, 0, st, a);
+    } else {
+        if (invd) hipLaunchKernelGGL((render_fwd_kernel<0, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((render_fwd_kernel<0, false>), grid, block, 0, st, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace gs

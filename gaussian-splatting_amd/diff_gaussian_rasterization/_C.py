@@ -1,0 +1,150 @@
+"""Host side of the rasterizer operator: the three functions the reference's
+pybind module exports (submodules/diff-gaussian-rasterization/ext.cpp:15-19,
+rasterize_points.cu:35-365), with the same argument order and return tuples,
+implemented over the C ABI of libgsplat_amd.so.
+"""
+import ctypes as C
+
+import torch
+
+from _gsplat_lib import (GsrBackwardIO, GsrForwardOut, GsrScene, check, dev_f32, lib, ptr, stream_of)
+
+SUPPORTED_DIMS = (0, 4)
+
+
+def _scene(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+           tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, antialiasing, debug, reps, keep):
+    dev = means3D.device
+    P = means3D.size(0)
+    s = GsrScene()
+    t = dict(bg=bg, means3D=means3D, shs=sh, colors_precomp=colors, opacities=opacity, scales=scales,
+             rotations=rotations, cov3D_precomp=cov3D_precomp, reps=reps, viewmatrix=viewmatrix,
+             projmatrix=projmatrix, campos=campos)
+    for name, ten in t.items():
+        c = dev_f32(ten, dev, name)
+        keep.append(c)
+        setattr(s, name, ptr(c))
+    s.P, s.D, s.W, s.H = P, int(degree), int(W), int(H)
+    s.M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
+    s.DIM = int(reps.size(1)) if (reps is not None and reps.numel() != 0) else 0
+    s.scale_modifier, s.tanfovx, s.tanfovy = float(scale_modifier), float(tan_fovx), float(tan_fovy)
+    s.prefiltered, s.antialiasing, s.debug = int(bool(prefiltered)), int(bool(antialiasing)), int(bool(debug))
+    return s
+
+
+def _check_shapes(means3D, reps):
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if reps is not None and reps.numel() != 0:
+        if reps.dim() != 2 or reps.size(0) != means3D.size(0) or reps.size(1) not in SUPPORTED_DIMS:
+            raise RuntimeError("reps must have dimensions (num_points, NUM_DIM) with NUM_DIM in %s" %
+                               (SUPPORTED_DIMS,))
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, antialiasing, debug, reps=None):
+    """rasterize_points.cu:35-206.  Returns (num_rendered, color, radii,
+    geomBuffer, binningBuffer, imgBuffer, invdepth, accum_alpha, gauss_sum,
+    gauss_count, last_contr_gauss, out_depths, out_reps)."""
+    _check_shapes(means3D, reps)
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a GPU tensor (there is no CPU path)")
+    L = lib()
+    dev = means3D.device
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    keep = []
+    with torch.cuda.device(dev):
+        s = _scene(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                   projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, antialiasing, debug, reps,
+                   keep)
+        DIM = s.DIM
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        out_color = torch.empty((3, H, W), **f32)
+        out_invdepth = torch.empty((1, H, W), **f32)
+        radii = torch.empty((P,), **i32)
+        accum_alpha = torch.empty((1, H, W), **f32)
+        gauss_sum = torch.empty((P,), **f32)
+        gauss_count = torch.empty((P,), **i32)
+        last_contr = torch.empty((1, H, W), **i32)
+        out_depths = torch.empty((P,), **f32)
+        out_reps = torch.empty((DIM, H, W), **f32)
+        geom = torch.empty((L.gsr_geom_bytes(P),), **u8)
+        img = torch.empty((L.gsr_image_bytes(W, H),), **u8)
+        o = GsrForwardOut()
+        o.out_color, o.out_invdepth, o.radii = ptr(out_color), ptr(out_invdepth), ptr(radii)
+        o.accum_alpha, o.gauss_sum, o.gauss_count = ptr(accum_alpha), ptr(gauss_sum), ptr(gauss_count)
+        o.last_contr_gauss, o.out_depths, o.out_reps = ptr(last_contr), ptr(out_depths), ptr(out_reps)
+        o.geom_buffer, o.geom_bytes = ptr(geom), geom.numel()
+        o.image_buffer, o.image_bytes = ptr(img), img.numel()
+        st = stream_of(dev)
+        R = C.c_int64(0)
+        check(L.gsr_forward_stage1(C.byref(s), C.byref(o), st, C.byref(R)), "rasterize_gaussians (stage 1)")
+        R = int(R.value)
+        binning = torch.empty((L.gsr_binning_bytes(R) if R > 0 else 0,), **u8)
+        check(L.gsr_forward_stage2(C.byref(s), C.byref(o), R, ptr(binning), binning.numel(), st),
+              "rasterize_gaussians (stage 2)")
+    return (R, out_color, radii, geom, binning, img, out_invdepth, accum_alpha, gauss_sum, gauss_count, last_contr,
+            out_depths, out_reps)
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                 dL_dout_invdepth, dL_dout_reps, sh, degree, campos, geomBuffer, R, binningBuffer,
+                                 imageBuffer, antialiasing, debug, reps=None):
+    """rasterize_points.cu:208-345.  Returns (dL_dmeans2D, dL_dcolors,
+    dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations,
+    dL_dreps)."""
+    L = lib()
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    keep = []
+    with torch.cuda.device(dev):
+        s = _scene(background, means3D, colors, opacities, scales, rotations, scale_modifier, cov3D_precomp,
+                   viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, False, antialiasing, debug,
+                   reps, keep)
+        M, DIM = s.M, s.DIM
+        f32 = dict(dtype=torch.float32, device=dev)
+        has_sr = scales is not None and scales.numel() != 0
+        e = torch.empty
+        dL_dmeans3D, dL_dmeans2D, dL_dcolors = e((P, 3), **f32), e((P, 3), **f32), e((P, 3), **f32)
+        dL_dopacity, dL_dcov3D, dL_dsh = e((P, 1), **f32), e((P, 6), **f32), e((P, M, 3), **f32)
+        dL_dscales = e((P, 3), **f32) if has_sr else torch.zeros((P, 3), **f32)
+        dL_drotations = e((P, 4), **f32) if has_sr else torch.zeros((P, 4), **f32)
+        dL_dreps = e((P, DIM), **f32)
+        if P != 0:
+            gc = dev_f32(dL_dout_color, dev, "dL_dout_color")
+            gd = dev_f32(dL_dout_invdepth, dev, "dL_dout_invdepth")
+            gr = dev_f32(dL_dout_reps, dev, "dL_dout_reps") if DIM else None
+            if DIM and gr is None:
+                gr = torch.zeros((DIM, H, W), **f32)
+            work = torch.empty((L.gsr_backward_work_bytes(P),), dtype=torch.uint8, device=dev)
+            io = GsrBackwardIO()
+            io.dL_dout_color, io.dL_dout_invdepth, io.dL_dout_reps = ptr(gc), ptr(gd), ptr(gr)
+            io.dL_dmeans2D, io.dL_dcolors, io.dL_dopacity = ptr(dL_dmeans2D), ptr(dL_dcolors), ptr(dL_dopacity)
+            io.dL_dmeans3D, io.dL_dcov3D, io.dL_dsh = ptr(dL_dmeans3D), ptr(dL_dcov3D), ptr(dL_dsh)
+            io.dL_dscales = ptr(dL_dscales) if has_sr else None
+            io.dL_drotations = ptr(dL_drotations) if has_sr else None
+            io.dL_dreps = ptr(dL_dreps)
+            io.work, io.work_bytes = ptr(work), work.numel()
+            check(L.gsr_backward(C.byref(s), ptr(radii), ptr(geomBuffer), ptr(binningBuffer), ptr(imageBuffer),
+                                 int(R), C.byref(io), stream_of(dev)), "rasterize_gaussians_backward")
+    return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dreps)
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """rasterize_points.cu:347-365."""
+    L = lib()
+    dev = means3D.device
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P != 0:
+        with torch.cuda.device(dev):
+            m = dev_f32(means3D, dev, "means3D")
+            v = dev_f32(viewmatrix, dev, "viewmatrix")
+            pm = dev_f32(projmatrix, dev, "projmatrix")
+            check(L.gsr_mark_visible(P, ptr(m), ptr(v), ptr(pm), present.data_ptr(), stream_of(dev)), "mark_visible")
+    return present

@@ -1,0 +1,167 @@
+/* C ABI of libgsplat_amd.so: the MI355X (gfx950) Gaussian rasterizer hot path.
+ *
+ * Every pointer named "device" is a device address on the GPU that is current
+ * when the call is made; `stream` is a hipStream_t passed as void*.  No entry
+ * point allocates or frees device memory: the caller brings every buffer
+ * (sizes from the gsr_*_bytes queries).  No torch types cross this boundary.
+ * All entry points return GSR_OK (0) or a negative GsrStatus and never throw.
+ *
+ * Reference interface replaced (paths under
+ * submodules/diff-gaussian-rasterization/ unless stated otherwise):
+ *   gsr_forward_stage1 + gsr_forward_stage2
+ *        CudaRasterizer::Rasterizer::forward   cuda_rasterizer/rasterizer.h:31-66,
+ *                                              cuda_rasterizer/rasterizer_impl.cu:197-433
+ *        (split in two because the binning buffer size is only known after the
+ *         prefix sum; the reference resizes it through a callback at
+ *         rasterizer_impl.cu:349-353)
+ *   gsr_backward
+ *        CudaRasterizer::Rasterizer::backward  cuda_rasterizer/rasterizer.h:68-102,
+ *                                              cuda_rasterizer/rasterizer_impl.cu:437-577
+ *   gsr_mark_visible
+ *        CudaRasterizer::Rasterizer::markVisible  cuda_rasterizer/rasterizer.h:24-29
+ *   gsr_geom_bytes / gsr_image_bytes / gsr_binning_bytes
+ *        required<GeometryState|ImageState|BinningState>  cuda_rasterizer/rasterizer_impl.h:64-72
+ *   gsr_sort_pairs_u64_u32
+ *        cub::DeviceRadixSort::SortPairs call site  cuda_rasterizer/rasterizer_impl.cu:373-380
+ *   gsk_dist2
+ *        SimpleKNN::knn   submodules/simple-knn/simple_knn.h, simple_knn.cu:186-222
+ *   gss_ssim_forward / gss_ssim_backward
+ *        fusedssim / fusedssim_backward   submodules/fused-ssim/ssim.cu:368-444
+ */
+#ifndef GSPLAT_AMD_H
+#define GSPLAT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    GSR_OK = 0,
+    GSR_ERR_ARG = -1,        /* null / inconsistent argument */
+    GSR_ERR_DIM = -2,        /* unsupported number of `reps` channels (supported: 0, 4) */
+    GSR_ERR_OVERFLOW = -3,   /* number of (Gaussian, tile) instances >= 2^30 */
+    GSR_ERR_BUFFER = -4,     /* a caller buffer is smaller than the matching *_bytes query */
+    GSR_ERR_HIP = -5,        /* a HIP runtime call failed */
+    GSR_ERR_SORT = -6        /* radix sort look-back did not complete */
+} GsrStatus;
+
+/* Inputs of one view.  Nullable pointers select the options exactly as the
+ * reference does: shs XOR colors_precomp, (scales AND rotations) XOR
+ * cov3D_precomp; reps is NULL iff DIM == 0. */
+typedef struct {
+    int P;                 /* number of Gaussians */
+    int D;                 /* active SH degree */
+    int M;                 /* SH coefficients allocated per Gaussian */
+    int DIM;               /* channels of `reps` (0 or 4) */
+    int W, H;              /* image size in pixels */
+    const float* bg;              /* device [3] */
+    const float* means3D;         /* device [P,3] */
+    const float* shs;             /* device [P,M,3] or NULL */
+    const float* colors_precomp;  /* device [P,3] or NULL */
+    const float* opacities;       /* device [P] */
+    const float* scales;          /* device [P,3] or NULL */
+    const float* rotations;       /* device [P,4] or NULL */
+    const float* cov3D_precomp;   /* device [P,6] or NULL */
+    const float* reps;            /* device [P,DIM] or NULL */
+    const float* viewmatrix;      /* device [16], as scene/cameras.py:86 stores it */
+    const float* projmatrix;      /* device [16], full projection, scene/cameras.py:88 */
+    const float* campos;          /* device [3] */
+    float scale_modifier;
+    float tanfovx, tanfovy;
+    int prefiltered;
+    int antialiasing;
+    int debug;             /* nonzero: synchronise and check for errors after every launch */
+} GsrScene;
+
+/* Outputs of the forward pass.  None of them needs initialising by the caller. */
+typedef struct {
+    float* out_color;        /* device [3,H,W] */
+    float* out_invdepth;     /* device [H,W] or NULL (then no inverse depth is rendered) */
+    int* radii;              /* device [P] */
+    float* accum_alpha;      /* device [H,W]: final transmittance per pixel */
+    float* gauss_sum;        /* device [P] */
+    int* gauss_count;        /* device [P] */
+    int* last_contr_gauss;   /* device [H,W], -1 where nothing contributed */
+    float* out_depths;       /* device [P]; written only where radii > 0 */
+    float* out_reps;         /* device [DIM,H,W] or NULL */
+    void* geom_buffer;       /* device, >= gsr_geom_bytes(P) */
+    size_t geom_bytes;
+    void* image_buffer;      /* device, >= gsr_image_bytes(W,H) */
+    size_t image_bytes;
+} GsrForwardOut;
+
+/* Gradients.  Inputs are the three per-pixel gradients; every output is fully
+ * written by the call (no zero-fill needed).  `work` is scratch. */
+typedef struct {
+    const float* dL_dout_color;     /* device [3,H,W] */
+    const float* dL_dout_invdepth;  /* device [H,W] or NULL */
+    const float* dL_dout_reps;      /* device [DIM,H,W] or NULL iff DIM == 0 */
+    float* dL_dmeans2D;      /* device [P,3] (z stays 0) */
+    float* dL_dcolors;       /* device [P,3] */
+    float* dL_dopacity;      /* device [P] */
+    float* dL_dmeans3D;      /* device [P,3] */
+    float* dL_dcov3D;        /* device [P,6] */
+    float* dL_dsh;           /* device [P,M,3] or NULL iff M == 0 */
+    float* dL_dscales;       /* device [P,3] or NULL iff scales == NULL */
+    float* dL_drotations;    /* device [P,4] or NULL iff rotations == NULL */
+    float* dL_dreps;         /* device [P,DIM] or NULL iff DIM == 0 */
+    void* work;              /* device, >= gsr_backward_work_bytes(P) */
+    size_t work_bytes;
+} GsrBackwardIO;
+
+size_t gsr_geom_bytes(int P);
+size_t gsr_image_bytes(int W, int H);
+size_t gsr_binning_bytes(int64_t num_rendered);
+size_t gsr_backward_work_bytes(int P);
+
+/* Preprocess + prefix sum.  Blocks the host once (as the reference does,
+ * rasterizer_impl.cu:338-346) to return the instance count in *num_rendered. */
+int gsr_forward_stage1(const GsrScene* scene, const GsrForwardOut* out, void* stream, int64_t* num_rendered);
+
+/* Key emission, sort, tile ranges, blending.  binning_buffer must hold
+ * gsr_binning_bytes(num_rendered) and be kept for the backward pass. */
+int gsr_forward_stage2(const GsrScene* scene, const GsrForwardOut* out, int64_t num_rendered, void* binning_buffer,
+                       size_t binning_bytes, void* stream);
+
+int gsr_backward(const GsrScene* scene, const int* radii, const void* geom_buffer, const void* binning_buffer,
+                 const void* image_buffer, int64_t num_rendered, const GsrBackwardIO* io, void* stream);
+
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream);
+
+/* Stable LSD radix sort of (u64 key, u32 value) pairs on key bits [0, end_bit).
+ * Both buffer pairs are clobbered; on return *result_buffer (0 or 1) says which
+ * pair holds the sorted data. */
+size_t gsr_sort_temp_bytes(int64_t n);
+int gsr_sort_pairs_u64_u32(uint64_t* keys0, uint32_t* vals0, uint64_t* keys1, uint32_t* vals1, int64_t n, int end_bit,
+                           void* temp, size_t temp_bytes, void* stream, int* result_buffer);
+
+/* Debug / test access: byte offsets of the arrays inside the scratch buffers. */
+typedef struct {
+    size_t rec, cov3D, tiles, clamped, block_sums, total;           /* geometry buffer */
+    size_t final_T, n_contrib, ranges;                               /* image buffer */
+    size_t keys0, keys1, vals0, vals1;                               /* binning buffer */
+    int sorted_buffer;                                               /* which keys/vals pair is sorted */
+} GsrLayout;
+int gsr_layout(int P, int W, int H, int64_t num_rendered, GsrLayout* out);
+
+/* simple-knn: mean squared distance to the 3 nearest neighbours. */
+size_t gsk_dist2_temp_bytes(int P);
+int gsk_dist2(int P, const float* points, float* mean_dists, void* temp, size_t temp_bytes, void* stream);
+
+/* fused-ssim.  The derivative maps may be NULL in the forward (train = false). */
+int gss_ssim_forward(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2,
+                     float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream);
+int gss_ssim_backward(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2,
+                      const float* dL_dmap, float* dL_dimg1, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                      const float* dm_dsigma12, void* stream);
+
+const char* gsr_status_string(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

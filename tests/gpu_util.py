@@ -1,0 +1,68 @@
+"""Helpers for the GPU parity tests: run a synthetic scene through the
+operator package (which goes through the C ABI of libgsplat_amd.so) and read
+the scratch buffers back for bit-exact comparison with the CPU checker."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+
+def scene_to_torch(sc, device="cuda:0", bg=(0.0, 0.0, 0.0), antialiasing=False, debug=True, scale_modifier=1.0):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    cam = sc["camera"]
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=device)
+    rs = GaussianRasterizationSettings(
+        image_height=cam["image_height"], image_width=cam["image_width"], tanfovx=cam["tanfovx"],
+        tanfovy=cam["tanfovy"], bg=t(bg), scale_modifier=scale_modifier, viewmatrix=t(cam["viewmatrix"]),
+        projmatrix=t(cam["projmatrix"]), sh_degree=sc["sh_degree"], campos=t(cam["campos"]), prefiltered=False,
+        debug=debug, antialiasing=antialiasing)
+    ten = {k: t(sc[k]) for k in ("means3D", "scales", "rotations", "opacities", "shs", "reps")}
+    return rs, ten
+
+
+def run_forward_raw(rs, ten, colors_precomp=None, cov3D_precomp=None, with_reps=True):
+    """Calls the pybind-level mirror and returns its 13-tuple as a dict."""
+    from diff_gaussian_rasterization import _C
+    e = torch.Tensor([])
+    out = _C.rasterize_gaussians(
+        rs.bg, ten["means3D"], e if colors_precomp is None else colors_precomp, ten["opacities"],
+        ten["scales"] if cov3D_precomp is None else e, ten["rotations"] if cov3D_precomp is None else e,
+        rs.scale_modifier, e if cov3D_precomp is None else cov3D_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+        rs.tanfovy, rs.image_height, rs.image_width, ten["shs"] if colors_precomp is None else e, rs.sh_degree,
+        rs.campos, rs.prefiltered, rs.antialiasing, rs.debug, ten["reps"] if with_reps else e)
+    names = ("num_rendered", "color", "radii", "geom", "binning", "img", "invdepth", "accum_alpha", "gauss_sum",
+             "gauss_count", "last_contr_gauss", "out_depths", "out_reps")
+    return dict(zip(names, out))
+
+
+def read_internals(out, P, W, H):
+    """Views into the scratch buffers (numpy copies)."""
+    from _gsplat_lib import GsrLayout, lib
+    R = out["num_rendered"]
+    lay = GsrLayout()
+    assert lib().gsr_layout(P, W, H, R, C.byref(lay)) == 0
+    geom, img, binning = out["geom"].cpu().numpy(), out["img"].cpu().numpy(), out["binning"].cpu().numpy()
+    ntiles = ((W + 15) // 16) * ((H + 15) // 16)
+    res = {}
+    res["rec"] = geom[lay.rec:lay.rec + P * 64].view(np.float32).reshape(P, 16)
+    res["cov3D"] = geom[lay.cov3D:lay.cov3D + P * 24].view(np.float32).reshape(P, 6)
+    res["bin"] = geom[lay.tiles:lay.tiles + P * 16].view(np.uint32).reshape(P, 4)
+    res["clamped"] = geom[lay.clamped:lay.clamped + P]
+    res["final_T"] = img[lay.final_T:lay.final_T + W * H * 4].view(np.float32)
+    res["n_contrib"] = img[lay.n_contrib:lay.n_contrib + W * H * 4].view(np.uint32)
+    res["ranges"] = img[lay.ranges:lay.ranges + ntiles * 8].view(np.uint32).reshape(ntiles, 2)
+    if R > 0:
+        k = (lay.keys0, lay.keys1)[lay.sorted_buffer]
+        v = (lay.vals0, lay.vals1)[lay.sorted_buffer]
+        res["keys"] = binning[k:k + R * 8].view(np.uint64)
+        res["point_list"] = binning[v:v + R * 4].view(np.uint32)
+    else:
+        res["keys"] = np.zeros(0, np.uint64)
+        res["point_list"] = np.zeros(0, np.uint32)
+    return res
+
+
+def rel_err(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
