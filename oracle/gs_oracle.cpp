@@ -553,6 +553,21 @@ void gso_sort_pairs(const uint64_t* kin, const uint32_t* vin, uint64_t* kout, ui
     radix_sort_pairs(kin, vin, kout, vout, n, end_bit);
 }
 
+// SH -> RGB (+0.5, clamp at 0) for N points, as preprocess does for a visible Gaussian.
+void gso_sh_eval(int N, int deg, int M, const float* pos, const float* campos, const float* shs, float* rgb,
+                 uint8_t* clamped) {
+    for (int i = 0; i < N; ++i) {
+        ShRow sh = {shs + (size_t)i * M * 3};
+        const V3 c = sh_to_rgb(deg, v3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]),
+                               v3(campos[0], campos[1], campos[2]), sh);
+        const float v[3] = {c.x, c.y, c.z};
+        for (int k = 0; k < 3; ++k) {
+            clamped[3 * i + k] = v[k] < 0;
+            rgb[3 * i + k] = fmax_(v[k], 0.0f);
+        }
+    }
+}
+
 void gso_expf(const float* x, float* y, int64_t n) {
     for (int64_t i = 0; i < n; ++i) y[i] = gs_expf(x[i]);
 }

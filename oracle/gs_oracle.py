@@ -75,6 +75,7 @@ def lib():
         _lib.gso_mark_visible.argtypes = [C.c_int, _fp, _fp, _fp, _bp]
         _lib.gso_sort_pairs.argtypes = [_u64p, _up, _u64p, _up, C.c_int64, C.c_int]
         _lib.gso_expf.argtypes = [_fp, _fp, C.c_int64]
+        _lib.gso_sh_eval.argtypes = [C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _bp]
         _lib.gso_dist2.argtypes = [C.c_int, _fp, _fp]
         _lib.gso_ssim_fwd.argtypes = [C.c_int] * 4 + [C.c_float] * 2 + [_fp] * 6
         _lib.gso_ssim_bwd.argtypes = [C.c_int] * 4 + [_fp] * 7
@@ -257,6 +258,15 @@ def expf(x):
     y = np.empty_like(x)
     lib().gso_expf(_f(x), _f(y), x.size)
     return y
+
+
+def sh_eval(deg, pos, campos, shs):
+    pos, campos, shs = _c(pos), _c(campos), _c(shs)
+    N, M = shs.shape[0], shs.shape[1]
+    rgb = np.zeros((N, 3), np.float32)
+    cl = np.zeros((N, 3), np.uint8)
+    lib().gso_sh_eval(N, int(deg), M, _f(pos), _f(campos), _f(shs), _f(rgb), cl.ctypes.data_as(_bp))
+    return rgb, cl
 
 
 def dist2(points):

@@ -1,0 +1,106 @@
+"""GPU parity for the stand-alone sort, simple-knn and fused-ssim kernels
+(through the C ABI) against the CPU checker.  Sort and knn are exact; ssim is
+the same arithmetic in the same order, so also exact up to the rounding of
+identical operations (asserted at 1e-6 absolute)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_sort(keys, vals, end_bit):
+    from _gsplat_lib import lib, ptr
+    L = lib()
+    n = keys.size
+    dev = "cuda:0"
+    k0 = torch.tensor(keys.view(np.int64), device=dev)
+    v0 = torch.tensor(vals.view(np.int32), device=dev)
+    k1, v1 = torch.empty_like(k0), torch.empty_like(v0)
+    temp = torch.empty(L.gsr_sort_temp_bytes(n), dtype=torch.uint8, device=dev)
+    res = C.c_int(0)
+    rc = L.gsr_sort_pairs_u64_u32(ptr(k0), ptr(v0), ptr(k1), ptr(v1), n, end_bit, ptr(temp), temp.numel(),
+                                  torch.cuda.current_stream().cuda_stream, C.byref(res))
+    assert rc == 0
+    torch.cuda.synchronize()
+    ko, vo = (k0, v0) if res.value == 0 else (k1, v1)
+    return ko.cpu().numpy().view(np.uint64), vo.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("n,end_bit", [(1, 64), (255, 13), (4096, 44), (4097, 47), (100_003, 45), (1_500_000, 47),
+                                       (70_000, 64), (9000, 8), (9000, 3)])
+def test_sort_pairs_bit_exact_and_stable(oracle, n, end_bit):
+    rng = np.random.default_rng(n + end_bit)
+    keys = rng.integers(0, 2 ** 63, size=n, dtype=np.int64).astype(np.uint64)
+    if end_bit < 64:
+        # few distinct values in the sorted bits => many ties => stability is visible in the values
+        keys = (keys & np.uint64((1 << end_bit) - 1)) if n < 10000 else (keys % np.uint64(50_000))
+        keys |= (rng.integers(0, 2 ** 15, size=n, dtype=np.int64).astype(np.uint64) << np.uint64(48)) if end_bit <= 47 else np.uint64(0)
+    vals = np.arange(n, dtype=np.uint32)
+    ko, vo = _gpu_sort(keys, vals, end_bit)
+    kr, vr = oracle.sort_pairs(keys, vals, end_bit)
+    assert np.array_equal(ko, kr)
+    assert np.array_equal(vo, vr)
+    mask = np.uint64((1 << end_bit) - 1) if end_bit < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    mk = ko & mask
+    assert np.all(mk[:-1] <= mk[1:])                                   # sortedness
+    same = mk[:-1] == mk[1:]
+    assert np.all(vo[:-1][same] < vo[1:][same])                        # stability
+    assert np.array_equal(np.sort(vo), vals)                           # permutation
+
+
+def test_sort_empty():
+    from _gsplat_lib import lib
+    res = C.c_int(5)
+    assert lib().gsr_sort_pairs_u64_u32(None, None, None, None, 0, 44, None, 0, None, C.byref(res)) == 0
+
+
+@pytest.mark.parametrize("P", [1, 3, 4, 700, 5000, 60_000])
+def test_dist2_exact(oracle, P):
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(P)
+    pts = (rng.standard_normal((P, 3)) * np.array([1.0, 0.3, 2.0]) + np.array([0.5, -2.0, 4.0])).astype(np.float32)
+    if P >= 700:
+        pts[::50] = pts[1::50][: len(pts[::50])]  # exact duplicates
+    got = distCUDA2(torch.tensor(pts, device="cuda:0")).cpu().numpy()
+    ref = oracle.dist2(pts)
+    assert np.array_equal(got, ref)
+    if 4 <= P <= 5000:  # brute force, independent of the box scheme
+        d = ((pts[:, None, :].astype(np.float32) - pts[None, :, :]) ** 2)
+        d2 = (d[..., 0] + d[..., 1]) + d[..., 2]
+        np.fill_diagonal(d2, np.inf)
+        part = np.sort(d2, axis=1)[:, :3].astype(np.float32)
+        bf = ((part[:, 0] + part[:, 1]) + part[:, 2]) / np.float32(3.0)
+        assert np.allclose(got, bf, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 37, 53), (2, 1, 64, 64), (1, 3, 200, 333), (1, 1, 5, 7)])
+@pytest.mark.parametrize("padding", ["same", "valid"])
+def test_fused_ssim_value_and_grad(oracle, shape, padding):
+    from fused_ssim import fused_ssim, fusedssim
+    if padding == "valid" and min(shape[2:]) <= 10:
+        pytest.skip("valid padding needs more than 10 pixels")
+    rng = np.random.default_rng(sum(shape))
+    a = rng.random(shape).astype(np.float32)
+    b = np.clip(a + 0.2 * rng.standard_normal(shape), 0, 1).astype(np.float32)
+    ta = torch.tensor(a, device="cuda:0", requires_grad=True)
+    tb = torch.tensor(b, device="cuda:0")
+    m, d1, d2, d3 = fusedssim(0.01 ** 2, 0.03 ** 2, ta.detach(), tb, True)
+    rm, r1, r2, r3 = oracle.ssim_fwd(a, b)
+    for g, r in ((m, rm), (d1, r1), (d2, r2), (d3, r3)):
+        assert np.abs(g.cpu().numpy() - r).max() <= 1e-6 * max(1.0, np.abs(r).max())
+    val = fused_ssim(ta, tb, padding=padding)
+    val.backward()
+    ref_map = rm if padding == "same" else rm[:, :, 5:-5, 5:-5]
+    assert abs(float(val) - float(ref_map.mean())) <= 1e-6
+    dl = np.full(shape, 1.0 / ref_map.size, np.float32)
+    if padding == "valid":
+        z = np.zeros(shape, np.float32)
+        z[:, :, 5:-5, 5:-5] = dl[:, :, 5:-5, 5:-5]
+        dl = z
+    rg = oracle.ssim_bwd(a, b, dl, r1, r2, r3)
+    assert np.abs(ta.grad.cpu().numpy() - rg).max() <= 1e-6 * max(1e-3, np.abs(rg).max())
+    m2, e1, _, _ = fusedssim(0.01 ** 2, 0.03 ** 2, ta.detach(), tb, False)
+    assert e1.numel() == 0 and torch.equal(m2, m)

@@ -1,0 +1,120 @@
+"""No-GPU checks of the product side: the C-ABI library loads and exports
+every symbol the header declares, size queries and argument validation work
+without a device, the Python operator layer mirrors the reference's checks,
+and there is no CPU fallback."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "gsplat_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(g(?:sr|sk|ss)_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from _gsplat_lib import EXPORTED, lib
+    L = lib()
+    names = _declared()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(EXPORTED) == names
+
+
+def test_size_queries_and_layout():
+    from _gsplat_lib import GsrLayout, lib
+    L = lib()
+    assert L.gsr_geom_bytes(0) < L.gsr_geom_bytes(1000) < L.gsr_geom_bytes(100000)
+    assert L.gsr_geom_bytes(6_000_000) >= 6_000_000 * (64 + 24 + 16 + 8 + 1)
+    assert L.gsr_image_bytes(1920, 1080) >= 1920 * 1080 * 8 + 8160 * 8
+    assert L.gsr_binning_bytes(10_000_000) >= 10_000_000 * 24
+    assert L.gsr_backward_work_bytes(1000) >= 64 * 1000
+    assert L.gsr_sort_temp_bytes(1 << 20) > 0
+    lay = GsrLayout()
+    assert L.gsr_layout(1000, 1297, 840, 12345, C.byref(lay)) == 0
+    offs = [lay.rec, lay.cov3D, lay.tiles, lay.clamped, lay.block_sums, lay.total]
+    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
+    assert lay.keys0 < lay.keys1 < lay.vals0 < lay.vals1
+    # 82 x 53 tiles -> 13 tile bits -> 45 key bits -> 6 passes -> result in buffer 0
+    assert lay.sorted_buffer == 0
+    assert L.gsr_layout(10, 16, 16, 0, C.byref(lay)) == 0 and lay.sorted_buffer == 1  # 33 bits -> 5 passes
+
+
+def test_argument_validation_without_gpu():
+    from _gsplat_lib import GsrBackwardIO, GsrForwardOut, GsrScene, lib
+    L = lib()
+    s, o = GsrScene(), GsrForwardOut()
+    R = C.c_int64(7)
+    s.P, s.W, s.H, s.DIM = 10, 0, 10, 0
+    assert L.gsr_forward_stage1(C.byref(s), C.byref(o), None, C.byref(R)) == -1       # bad image size
+    s.W = 10
+    s.DIM = 3
+    assert L.gsr_forward_stage1(C.byref(s), C.byref(o), None, C.byref(R)) == -2       # unsupported DIM
+    s.DIM = 0
+    assert L.gsr_forward_stage1(C.byref(s), C.byref(o), None, C.byref(R)) == -1       # null inputs
+    s.P = 0
+    assert L.gsr_forward_stage1(C.byref(s), C.byref(o), None, C.byref(R)) == 0 and R.value == 0
+    assert L.gsr_backward(C.byref(s), None, None, None, None, 0, C.byref(GsrBackwardIO()), None) == 0
+    assert L.gsr_mark_visible(0, None, None, None, None, None) == 0
+    assert L.gsr_mark_visible(5, None, None, None, None, None) == -1
+    assert L.gsk_dist2(0, None, None, None, 0, None) == 0
+    assert L.gsk_dist2(5, None, None, None, 0, None) == -1
+    assert L.gss_ssim_forward(1, 3, 0, 10, 1e-4, 9e-4, None, None, None, None, None, None, None) == 0
+    assert L.gss_ssim_forward(1, 3, 8, 8, 1e-4, 9e-4, None, None, None, None, None, None, None) == -1
+    res = C.c_int(0)
+    assert L.gsr_sort_pairs_u64_u32(None, None, None, None, 10, 44, None, 0, None, C.byref(res)) == -1
+    assert L.gsr_sort_pairs_u64_u32(None, None, None, None, 1 << 31, 44, None, 0, None, C.byref(res)) == -3
+    assert b"reps" in L.gsr_status_string(-2)
+
+
+def test_operator_layer_mirrors_reference_checks():
+    import diff_gaussian_rasterization as dgr
+    assert dgr.GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+        "sh_degree", "campos", "prefiltered", "debug", "antialiasing")
+    z = torch.zeros(3)
+    rs = dgr.GaussianRasterizationSettings(8, 8, 1.0, 1.0, z, 1.0, torch.eye(4), torch.eye(4), 0, z, False, False, False)
+    r = dgr.GaussianRasterizer(rs)
+    m = torch.zeros(4, 3)
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(means3D=m, means2D=m, opacities=torch.zeros(4, 1), scales=m, rotations=torch.zeros(4, 4))
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(means3D=m, means2D=m, opacities=torch.zeros(4, 1), shs=torch.zeros(4, 1, 3), colors_precomp=m, scales=m,
+          rotations=torch.zeros(4, 4))
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(means3D=m, means2D=m, opacities=torch.zeros(4, 1), shs=torch.zeros(4, 1, 3), scales=m)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(means3D=m, means2D=m, opacities=torch.zeros(4, 1), shs=torch.zeros(4, 1, 3), scales=m,
+          rotations=torch.zeros(4, 4), cov3D_precomp=torch.zeros(4, 6))
+    # CPU tensors are refused loudly: there is no CPU path
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r(means3D=m, means2D=m, opacities=torch.zeros(4, 1), shs=torch.zeros(4, 1, 3), scales=m,
+          rotations=torch.zeros(4, 4))
+    with pytest.raises(RuntimeError, match="num_points, 3"):
+        r(means3D=torch.zeros(4, 2), means2D=m, opacities=torch.zeros(4, 1), shs=torch.zeros(4, 1, 3), scales=m,
+          rotations=torch.zeros(4, 4))
+    import simple_knn._C as knn
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        knn.distCUDA2(torch.zeros(10, 3))
+    import fused_ssim
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        fused_ssim.fused_ssim(torch.zeros(1, 3, 16, 16), torch.zeros(1, 3, 16, 16))
+    with pytest.raises(AssertionError):
+        fused_ssim.fused_ssim(torch.zeros(1, 3, 16, 16), torch.zeros(1, 3, 16, 16), padding="full")
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "gaussian-splatting_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                assert "gs_oracle" not in txt and "oracle/" not in txt, os.path.join(d, f)
