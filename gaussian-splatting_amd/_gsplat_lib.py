@@ -21,7 +21,8 @@ class GsrScene(C.Structure):
                [(n, _vp) for n in ("bg", "means3D", "shs", "colors_precomp", "opacities", "scales", "rotations",
                                    "cov3D_precomp", "reps", "viewmatrix", "projmatrix", "campos")] + \
                [(n, C.c_float) for n in ("scale_modifier", "tanfovx", "tanfovy")] + \
-               [(n, C.c_int) for n in ("prefiltered", "antialiasing", "debug")]
+               [(n, C.c_int) for n in ("prefiltered", "antialiasing", "debug")] + \
+               [("profile_events", C.POINTER(C.c_void_p))]
 
 
 class GsrForwardOut(C.Structure):
@@ -96,6 +97,25 @@ EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backw
             "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_mark_visible", "gsr_sort_temp_bytes",
             "gsr_sort_pairs_u64_u32", "gsr_layout", "gsk_dist2_temp_bytes", "gsk_dist2", "gss_ssim_forward",
             "gss_ssim_backward", "gsr_status_string")
+
+
+NUM_PROFILE_EVENTS = 13
+EVENT_NAMES = ("stage1_begin", "preprocess", "scan", "stage2_begin", "emit", "sort", "ranges", "render", "finish",
+               "bwd_begin", "bwd_clear", "bwd_render", "bwd_preprocess")
+
+# Optional per-thread hook used by bench.py: a ctypes array of hipEvent_t handles
+# that the next rasterizer calls record around their kernels.
+_profile_events = None
+
+
+def set_profile_events(arr):
+    """arr: None, or (c_void_p * NUM_PROFILE_EVENTS) of hipEvent_t handles."""
+    global _profile_events
+    _profile_events = arr
+
+
+def profile_events():
+    return _profile_events
 
 
 def check(rc, what):

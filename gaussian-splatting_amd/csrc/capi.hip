@@ -19,6 +19,10 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? GSR_OK : GSR_ERR_
         }                                     \
     } while (0)
 
+inline void mark(const GsrScene* s, int slot, hipStream_t st) {
+    if (s->profile_events) (void)hipEventRecord((hipEvent_t)s->profile_events[slot], st);
+}
+
 int check_scene(const GsrScene* s) {
     if (!s || s->P < 0 || s->W <= 0 || s->H <= 0) return GSR_ERR_ARG;
     if (s->DIM != 0 && s->DIM != 4) return GSR_ERR_DIM;
@@ -60,8 +64,11 @@ int gsr_forward_stage1(const GsrScene* s, const GsrForwardOut* o, void* stream, 
     hipStream_t st = (hipStream_t)stream;
     const bool debug = s->debug != 0;
     const GeomBuf g = geom_buf(o->geom_buffer, (size_t)s->P);
+    mark(s, GSR_EV_STAGE1_BEGIN, st);
     GSR_TRY(launch_preprocess_fwd(*s, *o, g, st));
+    mark(s, GSR_EV_PREPROCESS, st);
     GSR_TRY(launch_scan_blocks(g, s->P, st));
+    mark(s, GSR_EV_SCAN, st);
     uint64_t tot[2] = {0, 0};
     if (hipMemcpyAsync(tot, g.total, sizeof(tot), hipMemcpyDeviceToHost, st) != hipSuccess) return GSR_ERR_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return GSR_ERR_HIP;
@@ -97,15 +104,23 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
         }
         BinView b = bin_view(binning_buffer, (size_t)R);
         int res = 0;
+        mark(s, GSR_EV_STAGE2_BEGIN, st);
         if (R > 0) {
             GSR_TRY(launch_emit_keys(*s, g, b.keys[0], b.vals[0], st));
+            mark(s, GSR_EV_EMIT, st);
             GSR_TRY(launch_radix_sort(b.keys, b.vals, R, sort_end_bit(*s), b.sort_temp, st, &res));
+            mark(s, GSR_EV_SORT, st);
         }
         GSR_TRY(launch_tile_ranges(b.keys[res], R, im.ranges, ntiles, st));
+        mark(s, GSR_EV_RANGES, st);
         point_list = b.vals[res];
     }
     GSR_TRY(launch_render_fwd(*s, *o, g, im, point_list, st));
-    if (s->P > 0) GSR_TRY(launch_finish_gstat(g, s->P, o->gauss_sum, o->gauss_count, st));
+    mark(s, GSR_EV_RENDER, st);
+    if (s->P > 0) {
+        GSR_TRY(launch_finish_gstat(g, s->P, o->gauss_sum, o->gauss_count, st));
+        mark(s, GSR_EV_FINISH, st);
+    }
     if (debug && R > 0) {
         const SortTemp t = sort_temp_view(bin_view(binning_buffer, (size_t)R).sort_temp, (size_t)R,
                                           sort_passes_for(sort_end_bit(*s)));
@@ -134,13 +149,17 @@ int gsr_backward(const GsrScene* s, const int* radii, const void* geom_buffer, c
     const GeomBuf g = geom_buf(geom_buffer, (size_t)s->P);
     const ImageView im = image_view((void*)image_buffer, (size_t)s->W, (size_t)s->H);
     GradRec* acc = (GradRec*)io->work;
+    mark(s, GSR_EV_BWD_BEGIN, st);
     GSR_TRY(hipMemsetAsync(acc, 0, (size_t)s->P * sizeof(GradRec), st));
+    mark(s, GSR_EV_BWD_CLEAR, st);
     if (R > 0) {
         const BinView b = bin_view((void*)binning_buffer, (size_t)R);
         const int res = sort_passes_for(sort_end_bit(*s)) & 1;
         GSR_TRY(launch_render_bwd(*s, g, im, b.vals[res], *io, acc, st));
     }
+    mark(s, GSR_EV_BWD_RENDER, st);
     GSR_TRY(launch_preprocess_bwd(*s, radii, g, *io, acc, st));
+    mark(s, GSR_EV_BWD_PREPROCESS, st);
     return GSR_OK;
 }
 

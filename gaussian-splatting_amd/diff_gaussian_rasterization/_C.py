@@ -7,7 +7,7 @@ import ctypes as C
 
 import torch
 
-from _gsplat_lib import (GsrBackwardIO, GsrForwardOut, GsrScene, check, dev_f32, lib, ptr, stream_of)
+from _gsplat_lib import (GsrBackwardIO, GsrForwardOut, GsrScene, check, dev_f32, lib, profile_events, ptr, stream_of)
 
 SUPPORTED_DIMS = (0, 4)
 
@@ -29,6 +29,9 @@ def _scene(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3
     s.DIM = int(reps.size(1)) if (reps is not None and reps.numel() != 0) else 0
     s.scale_modifier, s.tanfovx, s.tanfovy = float(scale_modifier), float(tan_fovx), float(tan_fovy)
     s.prefiltered, s.antialiasing, s.debug = int(bool(prefiltered)), int(bool(antialiasing)), int(bool(debug))
+    ev = profile_events()
+    if ev is not None:
+        s.profile_events = C.cast(ev, C.POINTER(C.c_void_p))
     return s
 
 

@@ -1,0 +1,86 @@
+"""View-sharded data parallelism for a training step (one process per GPU).
+
+The reference trains one view per iteration on one GPU (train.py:172-188) and
+has no distributed mode.  Views are independent given the parameters, so a
+multi-view batch shards by view with no exchange inside the rasterizer: every
+rank holds a full replica of the Gaussians, renders its slice of the batch and
+accumulates gradients locally; one sum all-reduce per parameter tensor (63
+floats per Gaussian with the fork's 4 `reps` channels) then makes every replica
+see the gradient of the whole batch.  `torch.distributed` backend "nccl" is
+RCCL on ROCm (xGMI between the GPUs of a node); "gloo" runs the same code on
+CPU tensors for tests.
+
+Densification statistics need the same treatment: the accumulated view-space
+gradient norms and visibility counts are sums over views, the maximum screen
+radius is a max (train.py:305-309, scene/gaussian_model.py:213-214).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_views(n_views, rank, world_size):
+    """Indices of the views rank `rank` renders: a contiguous, balanced split."""
+    base, extra = divmod(n_views, world_size)
+    start = rank * base + min(rank, extra)
+    return list(range(start, start + base + (1 if rank < extra else 0)))
+
+
+class GradReducer:
+    """Sums gradients over ranks with one asynchronous all-reduce per tensor,
+    largest first, on the process group's communication stream, so the
+    collectives of the big SH tensor overlap the launches of the small ones
+    and whatever the caller still runs before `wait()`."""
+
+    def __init__(self, group=None, average=False):
+        self.group = group
+        self.average = average
+        self.pending = []
+
+    def start(self, tensors):
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return self
+        for t in sorted((t for t in tensors if t is not None), key=lambda t: -t.numel()):
+            self.pending.append((t, dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+        return self
+
+    def wait(self):
+        ws = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        for t, work in self.pending:
+            work.wait()
+            if self.average:
+                t.div_(ws)
+        self.pending = []
+
+
+def reduce_densify_stats(xyz_gradient_accum, denom, max_radii2D, group=None):
+    """In-place reduction of the statistics densification reads."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    works = [dist.all_reduce(xyz_gradient_accum, op=dist.ReduceOp.SUM, group=group, async_op=True),
+             dist.all_reduce(denom, op=dist.ReduceOp.SUM, group=group, async_op=True),
+             dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX, group=group, async_op=True)]
+    for w in works:
+        w.wait()
+
+
+def view_sharded_step(params, views, loss_of_view, group=None):
+    """One multi-view step.  `params`: leaf tensors (requires_grad); `views`: the
+    whole batch (every rank passes the same list); `loss_of_view(view)` renders
+    one view from `params` and returns its scalar loss.  After the call each
+    param.grad holds the sum over ALL views of the batch on every rank.
+    Returns the local loss sum (a Python float is deliberately not produced:
+    no host sync)."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    for p in params:
+        p.grad = None
+    total = None
+    for vi in shard_views(len(views), rank, world):
+        loss = loss_of_view(views[vi])
+        loss.backward()
+        total = loss.detach() if total is None else total + loss.detach()
+    for p in params:  # a rank with no view (more ranks than views) contributes zeros
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    GradReducer(group).start([p.grad for p in params]).wait()
+    return total

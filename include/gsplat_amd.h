@@ -74,7 +74,28 @@ typedef struct {
     int prefiltered;
     int antialiasing;
     int debug;             /* nonzero: synchronise and check for errors after every launch */
+    void** profile_events; /* NULL, or GSR_NUM_PROFILE_EVENTS hipEvent_t handles that the calls record on
+                              `stream` around their kernels (see GsrProfileEvent); the caller reads the
+                              elapsed times after synchronising */
 } GsrScene;
+
+/* Slots of GsrScene.profile_events.  Each is recorded AFTER the named step. */
+typedef enum {
+    GSR_EV_STAGE1_BEGIN = 0,
+    GSR_EV_PREPROCESS = 1,     /* forward preprocess kernel */
+    GSR_EV_SCAN = 2,           /* block-sum scan */
+    GSR_EV_STAGE2_BEGIN = 3,
+    GSR_EV_EMIT = 4,           /* key emission */
+    GSR_EV_SORT = 5,           /* histogram + all onesweep passes */
+    GSR_EV_RANGES = 6,         /* tile ranges */
+    GSR_EV_RENDER = 7,         /* forward blend */
+    GSR_EV_FINISH = 8,         /* statistics unpack */
+    GSR_EV_BWD_BEGIN = 9,
+    GSR_EV_BWD_CLEAR = 10,     /* gradient accumulator clear */
+    GSR_EV_BWD_RENDER = 11,    /* backward blend */
+    GSR_EV_BWD_PREPROCESS = 12,/* per-Gaussian backward */
+    GSR_NUM_PROFILE_EVENTS = 13
+} GsrProfileEvent;
 
 /* Outputs of the forward pass.  None of them needs initialising by the caller. */
 typedef struct {
