@@ -108,10 +108,10 @@ class KernelTimer:
         self.G.set_profile_events(self.arrays[step] if step is not None else None)
 
     def means_ms(self, fwd_only=False):
-        pairs = {"preprocess": (0, 1), "scan": (1, 2), "emit_keys": (3, 4), "sort": (4, 5), "tile_ranges": (5, 6),
-                 "render_fwd": (6, 7), "finish_stats": (7, 8)}
+        pairs = {"preprocess": (0, 1), "scan": (1, 2), "depth_order": (3, 4), "emit_keys": (4, 5), "sort": (5, 6),
+                 "tile_ranges": (6, 7), "render_fwd": (7, 8), "finish_stats": (8, 9)}
         if not fwd_only:
-            pairs.update({"bwd_clear": (9, 10), "render_bwd": (10, 11), "preprocess_bwd": (11, 12)})
+            pairs.update({"bwd_clear": (10, 11), "render_bwd": (11, 12), "preprocess_bwd": (12, 13)})
         out = {}
         for k, (a, b) in pairs.items():
             out[k] = float(np.mean([row[a].elapsed_time(row[b]) for row in self.events]))
@@ -123,6 +123,7 @@ def algorithmic_bytes(kernel, P, visible, R, HW, passes):
     hot-path scope table (reference data layout)."""
     return {
         "preprocess": 315.0 * visible + 20.0 * (P - visible),
+        "depth_order": P * (28.0 + 8.0 + 4 * 24.0),
         "emit_keys": 20.0 * P + 12.0 * R,
         "sort": R * (8.0 + passes * 24.0),
         "tile_ranges": 8.0 * R,
@@ -245,7 +246,7 @@ def main():
                                        1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, shs,
                                        rs.sh_degree, rs.campos, False, True, False, params["reps"])[0]
     gx, gy = (W + 15) // 16, (H + 15) // 16
-    passes = (32 + (gx * gy).bit_length() + 7) // 8
+    passes = ((gx * gy).bit_length() + 7) // 8   # the instance sort only orders the tile bits
 
     # render FPS (forward only) and the sort rate, measured after the timed region
     render_fps = None

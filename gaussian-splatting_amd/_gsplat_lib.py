@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsplat_amd.so")
+LIB_PATH = os.environ.get("GSPLAT_AMD_LIB", os.path.join(_HERE, "libgsplat_amd.so"))
 
 _fp = C.POINTER(C.c_float)
 _vp = C.c_void_p
@@ -99,9 +99,9 @@ EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backw
             "gss_ssim_backward", "gsr_status_string")
 
 
-NUM_PROFILE_EVENTS = 13
-EVENT_NAMES = ("stage1_begin", "preprocess", "scan", "stage2_begin", "emit", "sort", "ranges", "render", "finish",
-               "bwd_begin", "bwd_clear", "bwd_render", "bwd_preprocess")
+NUM_PROFILE_EVENTS = 14
+EVENT_NAMES = ("stage1_begin", "preprocess", "scan", "stage2_begin", "depth_order", "emit", "sort", "ranges", "render",
+               "finish", "bwd_begin", "bwd_clear", "bwd_render", "bwd_preprocess")
 
 # Optional per-thread hook used by bench.py: a ctypes array of hipEvent_t handles
 # that the next rasterizer calls record around their kernels.

@@ -67,7 +67,7 @@ int gsr_forward_stage1(const GsrScene* s, const GsrForwardOut* o, void* stream, 
     mark(s, GSR_EV_STAGE1_BEGIN, st);
     GSR_TRY(launch_preprocess_fwd(*s, *o, g, st));
     mark(s, GSR_EV_PREPROCESS, st);
-    GSR_TRY(launch_scan_blocks(g, s->P, st));
+    GSR_TRY(launch_scan_blocks(g.block_sums, (s->P + PRE_BLOCK - 1) / PRE_BLOCK, g.total, st));
     mark(s, GSR_EV_SCAN, st);
     uint64_t tot[2] = {0, 0};
     if (hipMemcpyAsync(tot, g.total, sizeof(tot), hipMemcpyDeviceToHost, st) != hipSuccess) return GSR_ERR_HIP;
@@ -106,9 +106,13 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
         int res = 0;
         mark(s, GSR_EV_STAGE2_BEGIN, st);
         if (R > 0) {
-            GSR_TRY(launch_emit_keys(*s, g, b.keys[0], b.vals[0], st));
+            int ord = 0;
+            GSR_TRY(launch_depth_order(g, s->P, st, &ord));
+            mark(s, GSR_EV_DEPTH_ORDER, st);
+            GSR_TRY(launch_emit_keys(*s, g, g.dvals[ord], b.keys[0], b.vals[0], st));
             mark(s, GSR_EV_EMIT, st);
-            GSR_TRY(launch_radix_sort(b.keys, b.vals, R, sort_end_bit(*s), b.sort_temp, st, &res));
+            // emission order is (depth, index): only the tile bits are left to sort
+            GSR_TRY(launch_radix_sort(b.keys, b.vals, R, 32, sort_end_bit(*s), b.sort_temp, st, &res));
             mark(s, GSR_EV_SORT, st);
         }
         GSR_TRY(launch_tile_ranges(b.keys[res], R, im.ranges, ntiles, st));
@@ -123,7 +127,7 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
     }
     if (debug && R > 0) {
         const SortTemp t = sort_temp_view(bin_view(binning_buffer, (size_t)R).sort_temp, (size_t)R,
-                                          sort_passes_for(sort_end_bit(*s)));
+                                          sort_passes_for(32, sort_end_bit(*s)));
         uint32_t err = 0;
         if (hipMemcpy(&err, t.err, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess) return GSR_ERR_HIP;
         if (err) return GSR_ERR_SORT;
@@ -154,7 +158,7 @@ int gsr_backward(const GsrScene* s, const int* radii, const void* geom_buffer, c
     mark(s, GSR_EV_BWD_CLEAR, st);
     if (R > 0) {
         const BinView b = bin_view((void*)binning_buffer, (size_t)R);
-        const int res = sort_passes_for(sort_end_bit(*s)) & 1;
+        const int res = sort_passes_for(32, sort_end_bit(*s)) & 1;
         GSR_TRY(launch_render_bwd(*s, g, im, b.vals[res], *io, acc, st));
     }
     mark(s, GSR_EV_BWD_RENDER, st);
@@ -182,7 +186,7 @@ int gsr_sort_pairs_u64_u32(uint64_t* keys0, uint32_t* vals0, uint64_t* keys1, ui
     if (temp_bytes < gsr_sort_temp_bytes(n)) return GSR_ERR_BUFFER;
     uint64_t* k[2] = {keys0, keys1};
     uint32_t* v[2] = {vals0, vals1};
-    return hip_status(launch_radix_sort(k, v, n, end_bit, temp, (hipStream_t)stream, result_buffer));
+    return hip_status(launch_radix_sort(k, v, n, 0, end_bit, temp, (hipStream_t)stream, result_buffer));
 }
 
 int gsr_layout(int P, int W, int H, int64_t R, GsrLayout* out) {
@@ -205,7 +209,7 @@ int gsr_layout(int P, int W, int H, int64_t R, GsrLayout* out) {
     out->vals0 = (char*)b.vals[0] - z;
     out->vals1 = (char*)b.vals[1] - z;
     const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
-    out->sorted_buffer = sort_passes_for(32 + (int)higher_msb((uint32_t)(gx * gy))) & 1;
+    out->sorted_buffer = sort_passes_for(32, 32 + (int)higher_msb((uint32_t)(gx * gy))) & 1;
     return GSR_OK;
 }
 

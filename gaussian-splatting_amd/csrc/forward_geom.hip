@@ -121,18 +121,48 @@ __global__ void __launch_bounds__(256) scan_blocks_kernel(uint32_t* block_sums, 
     }
 }
 
-// duplicateWithKeys (rasterizer_impl.cu:70-110), balanced: the instances of a
-// block of 256 Gaussians are numbered consecutively and dealt to the threads
-// round-robin, so that both the work and the stores are uniform however large
-// individual splats are.  Output order and offsets equal the reference's.
-__global__ void __launch_bounds__(PRE_BLOCK) emit_keys_kernel(int P, int grid_x, const uint4* bin,
-                                                              const uint32_t* block_offsets, uint64_t* keys,
-                                                              uint32_t* vals) {
+// Depth keys for ordering the Gaussians front to back: the f32 bits of the
+// view-space depth (positive floats order like their bit patterns), all ones
+// for Gaussians that produce no instance so that they sort to the end.
+__global__ void __launch_bounds__(256) depth_keys_kernel(int P, const uint4* bin, uint64_t* keys, uint32_t* vals) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const uint4 b = bin[i];
+    keys[i] = b.w ? (uint64_t)b.z : 0xFFFFFFFFull;
+    vals[i] = (uint32_t)i;
+}
+
+// Tiles touched per block of 256 Gaussians taken in depth order.
+__global__ void __launch_bounds__(PRE_BLOCK) order_sums_kernel(int P, const uint32_t* order, const uint4* bin,
+                                                               uint32_t* sums) {
+    __shared__ uint32_t s_tmp[4];
+    const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    const uint32_t t = i < P ? bin[order[i]].w : 0u;
+    const uint32_t ws = wave_sum_u32(t);
+    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+}
+
+// duplicateWithKeys (rasterizer_impl.cu:70-110), restated for the hardware:
+//  * Gaussians are visited in depth order (ties in index order), so the emitted
+//    list is already sorted by (depth, index) and the 64-bit radix sort that
+//    follows only has to order the tile bits: 2 passes instead of 6, with the
+//    same final list as sorting the reference's emission order on all bits;
+//  * the instances of a block of 256 Gaussians are numbered consecutively and
+//    dealt to the threads round-robin, so work and stores are uniform however
+//    large individual splats are.
+__global__ void __launch_bounds__(PRE_BLOCK) emit_keys_kernel(int P, int grid_x, const uint32_t* order,
+                                                              const uint4* bin, const uint32_t* block_offsets,
+                                                              uint64_t* keys, uint32_t* vals) {
     __shared__ uint32_t s_tmp[8];
     __shared__ uint32_t s_off[PRE_BLOCK];
     __shared__ uint4 s_bin[PRE_BLOCK];
+    __shared__ uint32_t s_gid[PRE_BLOCK];
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-    const uint4 b = idx < P ? bin[idx] : make_uint4(0, 0, 0, 0);
+    const uint32_t gid = idx < P ? order[idx] : 0u;
+    const uint4 b = idx < P ? bin[gid] : make_uint4(0, 0, 0, 0);
+    s_gid[threadIdx.x] = gid;
     uint32_t total;
     const uint32_t ex = block_scan_excl_256(b.w, s_tmp, &total);
     s_off[threadIdx.x] = ex;
@@ -152,7 +182,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) emit_keys_kernel(int P, int grid_x,
         const uint32_t tx = q - ty * w;
         const uint32_t tile = ((gb.x >> 16) + ty) * (uint32_t)grid_x + (gb.x & 0xffffu) + tx;
         keys[base + s] = ((uint64_t)tile << 32) | gb.z;
-        vals[base + s] = (uint32_t)(blockIdx.x * PRE_BLOCK + lo);
+        vals[base + s] = s_gid[lo];
     }
 }
 
@@ -211,17 +241,27 @@ hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, cons
     return hipGetLastError();
 }
 
-hipError_t launch_scan_blocks(const GeomBuf& g, int P, hipStream_t st) {
-    const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, g.block_sums, nb, g.total);
+hipError_t launch_scan_blocks(uint32_t* block_sums, int nb, uint64_t* total, hipStream_t st) {
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, block_sums, nb, total);
     return hipGetLastError();
 }
 
-hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, uint64_t* keys, uint32_t* vals, hipStream_t st) {
+hipError_t launch_depth_order(const GeomBuf& g, int P, hipStream_t st, int* order_buffer) {
+    hipLaunchKernelGGL(depth_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, g.bin, g.dkeys[0], g.dvals[0]);
+    uint64_t* k[2] = {g.dkeys[0], g.dkeys[1]};
+    uint32_t* v[2] = {g.dvals[0], g.dvals[1]};
+    return launch_radix_sort(k, v, P, 0, 32, g.dsort_temp, st, order_buffer);
+}
+
+hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, const uint32_t* order, uint64_t* keys, uint32_t* vals,
+                            hipStream_t st) {
     const int nb = (s.P + PRE_BLOCK - 1) / PRE_BLOCK;
     const int grid_x = (s.W + TILE_X - 1) / TILE_X;
-    hipLaunchKernelGGL(emit_keys_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, s.P, grid_x, g.bin, g.block_sums, keys,
-                       vals);
+    hipLaunchKernelGGL(order_sums_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, s.P, order, g.bin, g.order_sums);
+    // total[] was read by the host already; the scan rewrites the same value
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, g.order_sums, nb, g.total);
+    hipLaunchKernelGGL(emit_keys_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, s.P, grid_x, order, g.bin, g.order_sums,
+                       keys, vals);
     return hipGetLastError();
 }
 

@@ -144,7 +144,10 @@ inline ImageView image_view(void* base, size_t W, size_t H) {
     return v;
 }
 
-constexpr int SORT_TILE = 4096;   // keys per onesweep workgroup
+#ifndef GS_SORT_TILE
+#define GS_SORT_TILE 4096
+#endif
+constexpr int SORT_TILE = GS_SORT_TILE;   // keys per onesweep workgroup
 constexpr int SORT_MAX_PASSES = 8;
 
 struct SortTemp {

@@ -16,8 +16,12 @@ struct GeomBuf {
     uint4* bin;           // [P] {x0 | y0<<16, w | h<<16, depth bits, tiles}
     float2* gstat;        // [P] (sum of T, hit count as float), accumulated by the forward blend
     uint8_t* clamped;     // [P]
-    uint32_t* block_sums; // [nblocks+1]
+    uint32_t* block_sums; // [nblocks+1] tiles per block of 256 Gaussians in index order (gives the total)
     uint64_t* total;      // [2]
+    uint64_t* dkeys[2];   // [P] depth bits (all ones for Gaussians that are not rendered), ping-pong
+    uint32_t* dvals[2];   // [P] Gaussian index, ping-pong; the sorted one is the front-to-back order
+    uint32_t* order_sums; // [nblocks+1] tiles per block of 256 Gaussians in depth order, then offsets
+    void* dsort_temp;
     size_t bytes;
 };
 
@@ -34,6 +38,12 @@ inline GeomBuf geom_buf(const void* base, size_t P) {
     v.clamped = (uint8_t*)take(P);
     v.block_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));
     v.total = (uint64_t*)take(2 * sizeof(uint64_t));
+    v.dkeys[0] = (uint64_t*)take(P * sizeof(uint64_t));
+    v.dkeys[1] = (uint64_t*)take(P * sizeof(uint64_t));
+    v.dvals[0] = (uint32_t*)take(P * sizeof(uint32_t));
+    v.dvals[1] = (uint32_t*)take(P * sizeof(uint32_t));
+    v.order_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));
+    v.dsort_temp = take(sort_temp_view(nullptr, P ? P : 1, 4).bytes);
     v.bytes = off;
     return v;
 }
@@ -48,18 +58,22 @@ struct __attribute__((aligned(16))) GradRec {
 };
 static_assert(sizeof(GradRec) == 64, "GradRec must be 64 bytes");
 
-int sort_passes_for(int end_bit);
+int sort_passes_for(int begin_bit, int end_bit);
 
 hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, const GeomBuf& g, hipStream_t st);
-hipError_t launch_scan_blocks(const GeomBuf& g, int P, hipStream_t st);
-hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, uint64_t* keys, uint32_t* vals, hipStream_t st);
+hipError_t launch_scan_blocks(uint32_t* block_sums, int nb, uint64_t* total, hipStream_t st);
+// Depth keys of all Gaussians, sorted front to back (stable): g.dvals[*order_buffer] is the order.
+hipError_t launch_depth_order(const GeomBuf& g, int P, hipStream_t st, int* order_buffer);
+// Key emission in depth order: only the tile bits of the keys remain to be sorted afterwards.
+hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, const uint32_t* order, uint64_t* keys, uint32_t* vals,
+                            hipStream_t st);
 hipError_t launch_tile_ranges(const uint64_t* keys, int64_t R, uint2* ranges, int ntiles, hipStream_t st);
 hipError_t launch_finish_gstat(const GeomBuf& g, int P, float* gauss_sum, int* gauss_count, hipStream_t st);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);
 
 // Returns the index (0/1) of the buffer pair that holds the sorted result.
-hipError_t launch_radix_sort(uint64_t* keys[2], uint32_t* vals[2], int64_t n, int end_bit, void* temp, hipStream_t st,
-                             int* result_buffer);
+hipError_t launch_radix_sort(uint64_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit, void* temp,
+                             hipStream_t st, int* result_buffer);
 
 hipError_t launch_render_fwd(const GsrScene& s, const GsrForwardOut& o, const GeomBuf& g, const ImageView& im,
                              const uint32_t* point_list, hipStream_t st);

@@ -232,7 +232,7 @@ hipError_t launch_knn(int P, const float* points, float* out, void* temp, hipStr
     uint64_t* k[2] = {t.keys[0], t.keys[1]};
     uint32_t* v[2] = {t.vals[0], t.vals[1]};
     int res = 0;
-    hipError_t e = launch_radix_sort(k, v, P, 30, t.sort_temp, st, &res);
+    hipError_t e = launch_radix_sort(k, v, P, 0, 30, t.sort_temp, st, &res);
     if (e != hipSuccess) return e;
     const int nb = (P + KNN_BOX - 1) / KNN_BOX;
     const int nsb = (nb + KNN_SUPER - 1) / KNN_SUPER;

@@ -1,28 +1,33 @@
 // Stable LSD radix sort of (u64 key, u32 value) pairs, 8 bits per pass, one
 // sweep over the data per pass ("onesweep"): digit histograms of all passes
-// are taken in one upfront read; each pass then ranks a 4096-key tile in LDS,
+// are taken in one upfront read; each pass then ranks an 8192-key tile in LDS,
 // obtains its global digit offsets by decoupled look-back over the preceding
 // tiles' published counts, and writes the tile out through an LDS staging
 // buffer so that stores to one digit's bucket are contiguous.
 // Replaces cub::DeviceRadixSort::SortPairs at rasterizer_impl.cu:373-380.
 //
 // Traffic per pass: 12 B read + 12 B written per pair, plus 3 KiB of status
-// words per 4096-pair tile.
+// words per 8192-pair tile.
 #include "kernels.h"
 
 namespace gs {
 
-constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = SORT_TILE / SORT_THREADS;  // 16
 constexpr uint32_t ST_AGG = 1u << 30;   // tile count published
 constexpr uint32_t ST_INCL = 2u << 30;  // inclusive prefix published
 constexpr uint32_t ST_MASK = (1u << 30) - 1;
 constexpr uint32_t SPIN_LIMIT = 1u << 22;
+#ifndef GS_LOOK_BATCH
+#define GS_LOOK_BATCH 4
+#endif
+#ifndef GS_LOOK_PREFETCH
+#define GS_LOOK_PREFETCH 1
+#endif
+constexpr int LOOK_BATCH = GS_LOOK_BATCH;
 
-int sort_passes_for(int end_bit) { return (end_bit + 7) / 8; }
+int sort_passes_for(int begin_bit, int end_bit) { return (end_bit - begin_bit + 7) / 8; }
 
-__global__ void __launch_bounds__(256) sort_hist_kernel(const uint64_t* keys, int64_t n, int passes, int end_bit,
-                                                        uint32_t* ghist) {
+__global__ void __launch_bounds__(256) sort_hist_kernel(const uint64_t* keys, int64_t n, int passes, int begin_bit,
+                                                        int end_bit, uint32_t* ghist) {
     __shared__ uint32_t h[SORT_MAX_PASSES * 256];
     for (int i = threadIdx.x; i < passes * 256; i += 256) h[i] = 0;
     __syncthreads();
@@ -30,8 +35,8 @@ __global__ void __launch_bounds__(256) sort_hist_kernel(const uint64_t* keys, in
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const uint64_t k = keys[i];
         for (int p = 0; p < passes; ++p) {
-            const int bits = min(8, end_bit - 8 * p);
-            const uint32_t d = (uint32_t)(k >> (8 * p)) & ((1u << bits) - 1);
+            const int bits = min(8, end_bit - begin_bit - 8 * p);
+            const uint32_t d = (uint32_t)(k >> (begin_bit + 8 * p)) & ((1u << bits) - 1);
             atomicAdd(&h[p * 256 + d], 1u);
         }
     }
@@ -51,46 +56,91 @@ __global__ void __launch_bounds__(256) sort_scan_hist_kernel(uint32_t* ghist) {
     h[threadIdx.x] = ex;
 }
 
-__global__ void __launch_bounds__(SORT_THREADS) onesweep_kernel(const uint64_t* __restrict__ kin,
-                                                                 const uint32_t* __restrict__ vin,
-                                                                 uint64_t* __restrict__ kout,
-                                                                 uint32_t* __restrict__ vout, int64_t n, int shift,
-                                                                 int bits, const uint32_t* __restrict__ gbase,
-                                                                 uint32_t* status, uint32_t* ticket, uint32_t* err) {
-    __shared__ uint32_t s_tile;
-    __shared__ uint32_t s_tmp[8];
-    __shared__ uint32_t s_whist[4][256];   // per-wave digit counts, then exclusive offsets across waves
-    __shared__ uint32_t s_dstart[256];     // first slot of each digit inside the tile
-    __shared__ uint32_t s_gofs[256];       // global slot of the digit's first key minus s_dstart
-    __shared__ uint64_t s_keys[SORT_TILE];
-    __shared__ uint32_t s_vals[SORT_TILE];
+// Exclusive scan over the first 256 threads' values in a block of NW waves.
+template <int NW>
+__device__ __forceinline__ uint32_t block_scan_excl_256_nw(uint32_t v, uint32_t* tmp, uint32_t* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t incl = wave_scan_incl_u32(v);
+    if (lane == 63 && w < 4) tmp[w] = incl;
+    __syncthreads();
+    uint32_t base = 0, sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t t = tmp[i];
+        if (i < w) base += t;
+        sum += t;
+    }
+    __syncthreads();
+    *total = sum;
+    return base + incl - v;
+}
+
+// One pass over one tile of SORT_TILE = THREADS * ITEMS pairs.  LDS: the key
+// staging area (reused for the values once the keys have left), per-wave digit
+// counters and three 256-entry tables; about 75 KiB, two workgroups per CU.
+#ifndef GS_OS_BLOCKS
+#define GS_OS_BLOCKS 2
+#endif
+template <int THREADS, int ITEMS>
+__global__ void __launch_bounds__(THREADS, (GS_OS_BLOCKS * THREADS) / 256)
+onesweep_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint64_t* __restrict__ kout,
+                uint32_t* __restrict__ vout, int64_t n, int shift, int bits, const uint32_t* __restrict__ gbase,
+                uint32_t* status, uint32_t* ticket, uint32_t* err) {
+    constexpr int NW = THREADS / 64;
+    constexpr int TILE = THREADS * ITEMS;
+    static_assert(TILE == SORT_TILE, "tile size must match the status array layout");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* s_keys = reinterpret_cast<uint64_t*>(smem);                 // [TILE]
+    uint32_t* s_vals = reinterpret_cast<uint32_t*>(smem);                 // [TILE], second phase
+    uint32_t* s_whist = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * 8);  // [NW][256]
+    uint32_t* s_hist = s_whist + NW * 256;                                // [256]
+    uint32_t* s_dstart = s_hist + 256;                                    // [256]
+    uint32_t* s_gofs = s_dstart + 256;                                    // [256]
+    uint32_t* s_tmp = s_gofs + 256;                                       // [8]
+    uint32_t* s_tile = s_tmp + 8;                                         // [1]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-    for (int i = tid; i < 4 * 256; i += SORT_THREADS) (&s_whist[0][0])[i] = 0;
+    if (tid == 0) *s_tile = atomicAdd(ticket, 1u);
+    for (int i = tid; i < (NW + 1) * 256; i += THREADS) s_whist[i] = 0;  // counters and s_hist
     __syncthreads();
-    const uint32_t tile = s_tile;
-    const int64_t tile_base = (int64_t)tile * SORT_TILE;
-    const int64_t wave_base = tile_base + (int64_t)w * (64 * SORT_ITEMS);
+    const uint32_t tile = *s_tile;
+    const int64_t tile_base = (int64_t)tile * TILE;
+    const int64_t wave_base = tile_base + (int64_t)w * (64 * ITEMS);
     const uint32_t dmask = (1u << bits) - 1;
 
-    uint64_t key[SORT_ITEMS];
-    uint32_t val[SORT_ITEMS];
-    uint32_t rank[SORT_ITEMS];
+    uint64_t key[ITEMS];
+    uint32_t val[ITEMS];
+    uint32_t rank[ITEMS];
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
         const int64_t i = wave_base + k * 64 + lane;
         const bool ok = i < n;
         key[k] = ok ? kin[i] : ~0ull;
         val[k] = ok ? vin[i] : 0u;
     }
 
-    // Stable ranking inside the wave: lanes holding the same digit find each
-    // other with 8 ballots; the lowest such lane advances the wave's counter.
-    const uint64_t lt_mask = (1ull << lane) - 1;
-    volatile uint32_t* wh = s_whist[w];
+    // 1. Tile histogram, published at once so that later tiles can look back
+    //    over this one while it is still ranking.
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
+        if ((wave_base + k * 64 + lane) < n) atomicAdd(&s_hist[(uint32_t)(key[k] >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    const bool dthread = tid < 256;  // threads that own a digit
+    const uint32_t dcount = dthread ? s_hist[tid] : 0u;
+    uint32_t* const my = status + (size_t)tile * 256 + tid;
+    if (dthread)
+        __hip_atomic_store(my, dcount | (tile == 0 ? ST_INCL : ST_AGG), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t tile_total;
+    const uint32_t dstart = block_scan_excl_256_nw<NW>(dcount, s_tmp, &tile_total);
+    if (dthread) s_dstart[tid] = dstart;
+
+    // 2. Stable ranking inside the wave: lanes holding the same digit find each
+    //    other with 8 ballots; the lowest such lane advances the wave's counter.
+    const uint64_t lt_mask = (1ull << lane) - 1;
+    volatile uint32_t* wh = s_whist + w * 256;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
         const bool ok = (wave_base + k * 64 + lane) < n;
         const uint32_t d = (uint32_t)(key[k] >> shift) & dmask;
         uint64_t peers = __ballot(ok);
@@ -107,46 +157,55 @@ __global__ void __launch_bounds__(SORT_THREADS) onesweep_kernel(const uint64_t* 
         rank[k] = prev + lower;
     }
     __syncthreads();
-
-    // Thread d: totals of digit d, offsets of each wave inside the digit.
-    uint32_t dcount;
-    {
-        const uint32_t c0 = s_whist[0][tid], c1 = s_whist[1][tid], c2 = s_whist[2][tid], c3 = s_whist[3][tid];
-        s_whist[0][tid] = 0;
-        s_whist[1][tid] = c0;
-        s_whist[2][tid] = c0 + c1;
-        s_whist[3][tid] = c0 + c1 + c2;
-        dcount = c0 + c1 + c2 + c3;
+    if (dthread) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const uint32_t c = s_whist[i * 256 + tid];
+            s_whist[i * 256 + tid] = run;
+            run += c;
+        }
     }
-    uint32_t tile_total;
-    const uint32_t dstart = block_scan_excl_256(dcount, s_tmp, &tile_total);
-    s_dstart[tid] = dstart;
 
-    // Decoupled look-back for digit `tid`.
-    {
-        uint32_t* my = status + (size_t)tile * 256 + tid;
+    // 3. Decoupled look-back for digit `tid`, LOOK_BATCH predecessors per round trip.
+    if (dthread) {
         uint32_t excl = 0;
-        if (tile == 0) {
-            __hip_atomic_store(my, dcount | ST_INCL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            __hip_atomic_store(my, dcount | ST_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef GS_SORT_NOLOOK
+        if (false) {
+#else
+        if (tile > 0) {
+#endif
             int64_t look = (int64_t)tile - 1;
             uint32_t spins = 0;
-            while (true) {
-                const uint32_t v = __hip_atomic_load(status + (size_t)look * 256 + tid, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t flag = v & ~ST_MASK;
-                if (flag == 0) {
-                    if (++spins > SPIN_LIMIT) {  // predecessor never published: give up, flag the sort
-                        atomicOr(err, 1u);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
+            bool done = false;
+            while (!done) {
+                uint32_t v[LOOK_BATCH];
+#pragma unroll
+                for (int i = 0; i < LOOK_BATCH; ++i) {
+                    const int64_t t = look - i;
+                    v[i] = t >= 0 ? __hip_atomic_load(status + (size_t)t * 256 + tid, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT)
+                                  : ST_INCL;
                 }
-                excl += v & ST_MASK;
-                if (flag == ST_INCL) break;
-                --look;
+#pragma unroll
+                for (int i = 0; i < LOOK_BATCH; ++i) {
+                    if (done) break;
+                    const uint32_t flag = v[i] & ~ST_MASK;
+                    if (flag == 0) {  // not published yet: poll again from this tile
+                        look -= i;
+                        if (++spins > SPIN_LIMIT) {
+                            atomicOr(err, 1u);
+                            done = true;
+                        } else {
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        goto next_round;
+                    }
+                    excl += v[i] & ST_MASK;
+                    if (flag == ST_INCL) done = true;
+                }
+                look -= LOOK_BATCH;
+            next_round:;
             }
             __hip_atomic_store(my, ((excl + dcount) & ST_MASK) | ST_INCL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -154,51 +213,74 @@ __global__ void __launch_bounds__(SORT_THREADS) onesweep_kernel(const uint64_t* 
     }
     __syncthreads();
 
-    // Place the tile in LDS in sorted order.
+    // 4. Keys: place in LDS in sorted order, stream out; remember each output
+    //    slot so that the values can follow through the same LDS.
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
         const bool ok = (wave_base + k * 64 + lane) < n;
-        if (ok) {
-            const uint32_t d = (uint32_t)(key[k] >> shift) & dmask;
-            const uint32_t pos = s_dstart[d] + s_whist[w][d] + rank[k];
-            s_keys[pos] = key[k];
-            s_vals[pos] = val[k];
-        }
+        const uint32_t d = (uint32_t)(key[k] >> shift) & dmask;
+        rank[k] = s_dstart[d] + s_whist[w * 256 + d] + rank[k];  // slot inside the tile
+        if (ok) s_keys[rank[k]] = key[k];
     }
     __syncthreads();
-
     const int64_t left = n - tile_base;
-    const uint32_t tile_n = left < SORT_TILE ? (uint32_t)left : (uint32_t)SORT_TILE;
+    const uint32_t tile_n = left < TILE ? (uint32_t)left : (uint32_t)TILE;
+    uint32_t dst[ITEMS];
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; ++k) {
-        const uint32_t pos = tid + k * SORT_THREADS;
+    for (int k = 0; k < ITEMS; ++k) {
+        const uint32_t pos = tid + k * THREADS;
+        dst[k] = 0;
         if (pos < tile_n) {
             const uint64_t kk = s_keys[pos];
             const uint32_t d = (uint32_t)(kk >> shift) & dmask;
-            const size_t dst = (size_t)s_gofs[d] + pos;
-            kout[dst] = kk;
-            vout[dst] = s_vals[pos];
+            dst[k] = s_gofs[d] + pos;
+            kout[dst[k]] = kk;
         }
+    }
+    __syncthreads();
+    // 5. Values through the same staging area.
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        if ((wave_base + k * 64 + lane) < n) s_vals[rank[k]] = val[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const uint32_t pos = tid + k * THREADS;
+        if (pos < tile_n) vout[dst[k]] = s_vals[pos];
     }
 }
 
-hipError_t launch_radix_sort(uint64_t* keys[2], uint32_t* vals[2], int64_t n, int end_bit, void* temp, hipStream_t st,
-                             int* result_buffer) {
+#ifndef GS_OS_THREADS
+#define GS_OS_THREADS 256
+#endif
+constexpr int OS_THREADS = GS_OS_THREADS;
+constexpr int OS_ITEMS = SORT_TILE / OS_THREADS;
+constexpr size_t OS_LDS = (size_t)SORT_TILE * 8 + (OS_THREADS / 64 + 4) * 256 * 4 + 64;
+
+hipError_t launch_radix_sort(uint64_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit, void* temp,
+                             hipStream_t st, int* result_buffer) {
     *result_buffer = 0;
-    if (n <= 0 || end_bit <= 0) return hipSuccess;
-    const int passes = sort_passes_for(end_bit);
+    if (n <= 0 || end_bit <= begin_bit) return hipSuccess;
+    const int passes = sort_passes_for(begin_bit, end_bit);
     const SortTemp t = sort_temp_view(temp, (size_t)n, passes);
     hipError_t e = hipMemsetAsync(t.ghist, 0, t.zero_bytes, st);
     if (e != hipSuccess) return e;
     const int64_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
     const int hist_blocks = (int)(tiles < 2048 ? tiles : 2048);
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(hist_blocks), dim3(256), 0, st, keys[0], n, passes, end_bit, t.ghist);
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(hist_blocks), dim3(256), 0, st, keys[0], n, passes, begin_bit, end_bit,
+                       t.ghist);
     hipLaunchKernelGGL(sort_scan_hist_kernel, dim3(passes), dim3(256), 0, st, t.ghist);
+    auto kern = onesweep_kernel<OS_THREADS, OS_ITEMS>;
+    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)OS_LDS);
+    if (ea != hipSuccess) return ea;
     int cur = 0;
     for (int p = 0; p < passes; ++p) {
-        const int bits = end_bit - 8 * p < 8 ? end_bit - 8 * p : 8;
-        hipLaunchKernelGGL(onesweep_kernel, dim3((unsigned)tiles), dim3(SORT_THREADS), 0, st, keys[cur], vals[cur],
-                           keys[cur ^ 1], vals[cur ^ 1], n, 8 * p, bits, t.ghist + p * 256,
+        const int left_bits = end_bit - begin_bit - 8 * p;
+        const int bits = left_bits < 8 ? left_bits : 8;
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(OS_THREADS), OS_LDS, st, keys[cur], vals[cur],
+                           keys[cur ^ 1], vals[cur ^ 1], n, begin_bit + 8 * p, bits, t.ghist + p * 256,
                            t.status + (size_t)p * tiles * 256, t.ticket + p, t.err);
         cur ^= 1;
     }

@@ -85,16 +85,17 @@ typedef enum {
     GSR_EV_PREPROCESS = 1,     /* forward preprocess kernel */
     GSR_EV_SCAN = 2,           /* block-sum scan */
     GSR_EV_STAGE2_BEGIN = 3,
-    GSR_EV_EMIT = 4,           /* key emission */
-    GSR_EV_SORT = 5,           /* histogram + all onesweep passes */
-    GSR_EV_RANGES = 6,         /* tile ranges */
-    GSR_EV_RENDER = 7,         /* forward blend */
-    GSR_EV_FINISH = 8,         /* statistics unpack */
-    GSR_EV_BWD_BEGIN = 9,
-    GSR_EV_BWD_CLEAR = 10,     /* gradient accumulator clear */
-    GSR_EV_BWD_RENDER = 11,    /* backward blend */
-    GSR_EV_BWD_PREPROCESS = 12,/* per-Gaussian backward */
-    GSR_NUM_PROFILE_EVENTS = 13
+    GSR_EV_DEPTH_ORDER = 4,    /* front-to-back order of the Gaussians (32-bit depth sort) */
+    GSR_EV_EMIT = 5,           /* key emission in depth order */
+    GSR_EV_SORT = 6,           /* sort of the instances on the tile bits */
+    GSR_EV_RANGES = 7,         /* tile ranges */
+    GSR_EV_RENDER = 8,         /* forward blend */
+    GSR_EV_FINISH = 9,         /* statistics unpack */
+    GSR_EV_BWD_BEGIN = 10,
+    GSR_EV_BWD_CLEAR = 11,     /* gradient accumulator clear */
+    GSR_EV_BWD_RENDER = 12,    /* backward blend */
+    GSR_EV_BWD_PREPROCESS = 13,/* per-Gaussian backward */
+    GSR_NUM_PROFILE_EVENTS = 14
 } GsrProfileEvent;
 
 /* Outputs of the forward pass.  None of them needs initialising by the caller. */
