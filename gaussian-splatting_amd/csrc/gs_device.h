@@ -61,6 +61,34 @@ __device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t v) {
     return v;
 }
 
+// Lane exchanges inside a row of 16 lanes (DPP, no LDS): value of lane ^ 1, ^ 2, ^ 4, ^ 8.
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_f<0xB1, 0xf>(v); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float lane_xor2(float v) { return dpp_f<0x4E, 0xf>(v); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ float lane_xor8(float v) { return dpp_f<0x128, 0xf>(v); }  // row_ror:8
+__device__ __forceinline__ float lane_xor4(float v) {
+    const int x = __builtin_bit_cast(int, v);
+    int t = __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xA, false);  // row_shr:4 into lanes 4-7, 12-15
+    t = __builtin_amdgcn_update_dpp(t, x, 0x104, 0xf, 0x5, false);      // row_shl:4 into lanes 0-3, 8-11
+    return __builtin_bit_cast(float, t);
+}
+
+// Transposing reduction of 16 per-lane values over a row of 16 lanes: on return
+// lane l holds the sum over its row of v[l & 15].  Each butterfly step halves
+// the number of live registers (a lane keeps the half whose index bit matches
+// its own lane bit and adds the partner's copy), 15 exchanges in all instead
+// of the 64 a value-by-value reduction needs.
+__device__ __forceinline__ float row_transpose_sum16(const float (&v)[16], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    float a[8], b[4], c[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (b0 ? v[2 * i + 1] : v[2 * i]) + lane_xor1(b0 ? v[2 * i] : v[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = (b1 ? a[2 * i + 1] : a[2 * i]) + lane_xor2(b1 ? a[2 * i] : a[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) c[i] = (b2 ? b[2 * i + 1] : b[2 * i]) + lane_xor4(b2 ? b[2 * i] : b[2 * i + 1]);
+    return (b3 ? c[1] : c[0]) + lane_xor8(b3 ? c[0] : c[1]);
+}
+
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0)); }
 
 // Block-wide exclusive scan of one u32 per thread, 256 threads.  `tmp` holds

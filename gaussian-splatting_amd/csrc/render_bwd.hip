@@ -3,11 +3,12 @@
 // Same tiling as the forward (16x16 tile, 4 wave64 quadrants); the tile's list
 // is walked back to front starting at the last instance any pixel of the tile
 // actually blended.  The reference issues up to 14 global float atomics per
-// (pixel, Gaussian) pair; here each gradient component is first summed over the
-// wave's 64 pixels with DPP adds, then over the four waves in LDS, and leaves
-// the workgroup once per (tile, instance) as a 64-byte GradRec update: 16 lanes
-// add to 16 consecutive floats, so one wave instruction carries four complete
-// line-half atomics instead of 64 scattered ones.
+// (pixel, Gaussian) pair; here the 14 gradient components of an instance are
+// summed over the wave's 64 pixels by a transposing DPP butterfly (15 lane
+// exchanges), over the four waves by LDS atomics, and leave the workgroup once
+// per (tile, instance) as a 64-byte GradRec update: 16 lanes add to 16
+// consecutive floats, so one wave instruction carries four complete line-half
+// atomics instead of 64 scattered ones.
 #include "kernels.h"
 
 namespace gs {
@@ -190,28 +191,12 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
                 g_cw = -0.5f * gdy * dy * dL_dG;
             }
 
-            float* dst = &s_acc[j][0];
-            float r;
-#define GS_RED(slot, v)                     \
-    r = wave_sum_lane63(v);                 \
-    if (lane == 63) atomicAdd(dst + slot, r);
-            GS_RED(0, g_mx)
-            GS_RED(1, g_my)
-            GS_RED(2, g_cx)
-            GS_RED(3, g_cy)
-            GS_RED(4, g_cw)
-            GS_RED(5, g_op)
-            GS_RED(6, g_c0)
-            GS_RED(7, g_c1)
-            GS_RED(8, g_c2)
-            if (INVD) { GS_RED(9, g_id) }
-            if (DIM == 4) {
-                GS_RED(10, g_rep[0])
-                GS_RED(11, g_rep[1])
-                GS_RED(12, g_rep[2])
-                GS_RED(13, g_rep[3])
-            }
-#undef GS_RED
+            // 16 gradient components x 64 pixels -> 16 sums: transpose-reduce inside each
+            // row of 16 lanes, then the four rows meet in one LDS atomic per lane.
+            const float comp[16] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_c0, g_c1, g_c2, g_id,
+                                    DIM == 4 ? g_rep[0] : 0.f, DIM == 4 ? g_rep[1] : 0.f,
+                                    DIM == 4 ? g_rep[2] : 0.f, DIM == 4 ? g_rep[3] : 0.f, 0.f, 0.f};
+            atomicAdd(&s_acc[j][lane & 15], row_transpose_sum16(comp, lane));
         }
         __syncthreads();
         // 16 lanes per instance: one 64-byte GradRec update
