@@ -1,15 +1,14 @@
 // Per-Gaussian backward: conic -> cov2D -> cov3D / mean (EWA), 2D mean -> 3D
 // mean, colour -> SH, cov3D -> scale / rotation.  Reference:
 // cuda_rasterizer/backward.cu:147-329 (computeCov2DCUDA) and :401-471
-// (preprocessCUDA).  HBM-bound.  Two kernels:
-//   sh_bwd_kernel         16 lanes per Gaussian, one SH coefficient per lane, so
-//                         the 192-byte SH rows are read and the 192-byte dL/dSH
-//                         rows written as contiguous lines; the direction
-//                         gradient is summed over the 16 lanes with DPP adds.
-//   preprocess_bwd_kernel one lane per Gaussian for everything else.
-// Together they read the 64-byte GradRec the blend backward filled plus the
-// Gaussian's inputs and write every gradient tensor completely (zeros for
-// Gaussians that were not rendered), so the caller never zero-fills.
+// (preprocessCUDA), which run as two kernels over the same data; here they are
+// one pass, one lane per Gaussian.  HBM-bound: reads the 64-byte GradRec the
+// blend backward filled plus the Gaussian's inputs and writes every gradient
+// tensor completely (zeros for Gaussians that were not rendered), so the caller
+// never zero-fills.  With the usual 16 SH coefficients the 192-byte SH rows come
+// in and the 192-byte dL/dSH rows go out through an LDS image, as whole
+// 16-byte chunks in address order (sh_rows_load / sh_rows_store); other SH
+// sizes use sh_bwd_kernel (16 lanes per Gaussian, one coefficient each).
 #include "kernels.h"
 
 namespace gs {
@@ -92,24 +91,15 @@ __global__ void __launch_bounds__(256) sh_bwd_kernel(const PreBwdArgs a) {
     }
 }
 
-__global__ void __launch_bounds__(256) preprocess_bwd_kernel(const PreBwdArgs a) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
-    const size_t i = (size_t)idx;
-    if (!(a.radii[idx] > 0)) {
-        a.dL_dmeans2D[3 * i] = a.dL_dmeans2D[3 * i + 1] = a.dL_dmeans2D[3 * i + 2] = 0.f;
-        a.dL_dcolors[3 * i] = a.dL_dcolors[3 * i + 1] = a.dL_dcolors[3 * i + 2] = 0.f;
-        a.dL_dopacity[i] = 0.f;
-        a.dL_dmeans3D[3 * i] = a.dL_dmeans3D[3 * i + 1] = a.dL_dmeans3D[3 * i + 2] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) a.dL_dcov3D[6 * i + k] = 0.f;
-        if (a.dL_dscales) {
-            a.dL_dscales[3 * i] = a.dL_dscales[3 * i + 1] = a.dL_dscales[3 * i + 2] = 0.f;
-            reinterpret_cast<float4*>(a.dL_drotations)[i] = make_float4(0, 0, 0, 0);
-        }
-        if (a.DIM == 4) reinterpret_cast<float4*>(a.dL_dreps)[i] = make_float4(0, 0, 0, 0);
-        return;
-    }
+struct ShRegs {
+    const float* v;
+    __device__ __forceinline__ V3 operator()(int k) const { return v3(v[3 * k], v[3 * k + 1], v[3 * k + 2]); }
+};
+
+// Everything for one rendered Gaussian.  LDS_SH: its SH row is in `lds` and its
+// dL/dSH row is left there; otherwise sh_bwd_kernel did the SH part.
+template <bool LDS_SH>
+__device__ __forceinline__ void pre_bwd_rendered(const PreBwdArgs& a, size_t i, float4* lds, int lane) {
     const Cam c = load_cam(a.cam, a.W, a.H, a.tanx, a.tany, a.mod, a.D, a.M, a.aa);
     const float4* gq = reinterpret_cast<const float4*>(a.acc + i);
     const float4 g0 = gq[0], g1 = gq[1], g2 = gq[2], g3 = gq[3];
@@ -125,7 +115,25 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(const PreBwdArgs a)
     V3 dmean = cov2d_bwd(c, mean, cov6, a.opacities[i], dconic, &dop, a.has_invdepth ? &dinv : nullptr, dcov6);
     dmean = add(dmean, mean2d_bwd(mean, c.proj, g0.x, g0.y));
 
-    if (a.shs) {  // direction term, left there by sh_bwd_kernel
+    if (LDS_SH) {
+        float shv[SH_ROW_F], dshv[SH_ROW_F];
+        sh_row_get(lds, lane, shv);
+        const uint8_t cl = a.clamped[i];
+        V3 gcol = v3(g1.z, g1.w, g2.x);
+        gcol.x *= (cl & 1) ? 0 : 1;
+        gcol.y *= (cl & 2) ? 0 : 1;
+        gcol.z *= (cl & 4) ? 0 : 1;
+#pragma unroll
+        for (int k = 0; k < SH_ROW_F; ++k) dshv[k] = 0.f;
+        auto out = [&dshv](int k, V3 v) {
+            dshv[3 * k] = v.x;
+            dshv[3 * k + 1] = v.y;
+            dshv[3 * k + 2] = v.z;
+        };
+        ShRegs sh = {shv};
+        dmean = add(dmean, sh_to_rgb_bwd(c.sh_degree, mean, v3(c.campos[0], c.campos[1], c.campos[2]), gcol, sh, out));
+        sh_row_put(lds, lane, dshv);  // only this lane touches its row between the two wave-wide copies
+    } else if (a.shs) {  // direction term, left there by sh_bwd_kernel
         dmean = add(dmean, v3(a.dL_dmeans3D[3 * i], a.dL_dmeans3D[3 * i + 1], a.dL_dmeans3D[3 * i + 2]));
     }
     if (a.scales) {
@@ -155,6 +163,52 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(const PreBwdArgs a)
     if (a.DIM == 4) reinterpret_cast<float4*>(a.dL_dreps)[i] = make_float4(g2.z, g2.w, g3.x, g3.y);
 }
 
+// A Gaussian the forward did not render: every gradient is zero.
+template <bool LDS_SH>
+__device__ __forceinline__ void pre_bwd_unrendered(const PreBwdArgs& a, size_t i, float4* lds, int lane) {
+    if (LDS_SH) {
+#pragma unroll
+        for (int ch = 0; ch < SH_ROW_CHUNKS; ++ch) lds[lane * SH_LDS_STRIDE + ch] = make_float4(0, 0, 0, 0);
+    }
+    a.dL_dmeans2D[3 * i] = a.dL_dmeans2D[3 * i + 1] = a.dL_dmeans2D[3 * i + 2] = 0.f;
+    a.dL_dcolors[3 * i] = a.dL_dcolors[3 * i + 1] = a.dL_dcolors[3 * i + 2] = 0.f;
+    a.dL_dopacity[i] = 0.f;
+    a.dL_dmeans3D[3 * i] = a.dL_dmeans3D[3 * i + 1] = a.dL_dmeans3D[3 * i + 2] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.dL_dcov3D[6 * i + k] = 0.f;
+    if (a.dL_dscales) {
+        a.dL_dscales[3 * i] = a.dL_dscales[3 * i + 1] = a.dL_dscales[3 * i + 2] = 0.f;
+        reinterpret_cast<float4*>(a.dL_drotations)[i] = make_float4(0, 0, 0, 0);
+    }
+    if (a.DIM == 4) reinterpret_cast<float4*>(a.dL_dreps)[i] = make_float4(0, 0, 0, 0);
+}
+
+// LDS_SH: shs is [P,16,3] and is handled inside this kernel through LDS;
+// otherwise the SH part was done by sh_bwd_kernel (or there are no SHs).
+template <bool LDS_SH>
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(const PreBwdArgs a) {
+    __shared__ float4 s_sh[LDS_SH ? 4 * SH_WAVE_LDS_F4 : 1];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wave_g0 = blockIdx.x * 256 + w * 64;  // first Gaussian of this wave
+    const int nrows = min(64, a.P - wave_g0);        // <= 0 for waves past the end
+    if (nrows <= 0) return;
+    const bool live = idx < a.P;
+    const bool rendered = live && a.radii[live ? idx : 0] > 0;
+    float4* lds = s_sh + (LDS_SH ? w * SH_WAVE_LDS_F4 : 0);
+    if (LDS_SH) {
+        const uint64_t rows = __ballot(rendered);
+        if (rows) sh_rows_load(a.shs + (size_t)wave_g0 * SH_ROW_F, lds, rows, nrows, lane);
+        wave_lds_sync();
+    }
+    if (rendered) pre_bwd_rendered<LDS_SH>(a, (size_t)idx, lds, lane);
+    else if (live) pre_bwd_unrendered<LDS_SH>(a, (size_t)idx, lds, lane);
+    if (LDS_SH) {
+        wave_lds_sync();
+        sh_rows_store(a.dL_dsh + (size_t)wave_g0 * SH_ROW_F, lds, nrows, lane);
+    }
+}
+
 hipError_t launch_preprocess_bwd(const GsrScene& s, const int* radii, const GeomBuf& g, const GsrBackwardIO& io,
                                  const GradRec* acc, hipStream_t st) {
     PreBwdArgs a;
@@ -171,11 +225,13 @@ hipError_t launch_preprocess_bwd(const GsrScene& s, const int* radii, const Geom
     a.dL_dscales = s.scales ? io.dL_dscales : nullptr;
     a.dL_drotations = s.scales ? io.dL_drotations : nullptr;
     a.dL_dreps = io.dL_dreps;
-    if (s.shs) {
+    const bool lds_sh = s.shs && s.M == 16;
+    if (s.shs && !lds_sh) {
         const size_t threads = (size_t)s.P * 16;
         hipLaunchKernelGGL(sh_bwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
     }
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((s.P + 255) / 256), dim3(256), 0, st, a);
+    if (lds_sh) hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((s.P + 255) / 256), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3((s.P + 255) / 256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

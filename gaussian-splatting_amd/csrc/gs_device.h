@@ -110,6 +110,65 @@ __device__ __forceinline__ uint32_t block_scan_excl_256(uint32_t v, uint32_t* tm
     return base + incl - v;
 }
 
+// ------------------------------------------------------------------ SH rows through LDS
+// The SH tensors are [P, 16, 3] floats: 192 bytes per Gaussian.  A lane that
+// walks its own row issues 48 strided dword accesses; instead each wave moves
+// the 12 KiB of its 64 consecutive rows as whole 16-byte chunks (coalesced)
+// through an LDS image and every lane then reads / writes its own row with
+// ds_read_b128 / ds_write_b128.  Rows are padded to 13 chunks: with an odd
+// chunk stride the 16 lanes that one ds_*_b128 group serves fall on 16
+// different 16-byte slots.
+constexpr int SH_ROW_F = 48;          // floats per row (M = 16)
+constexpr int SH_ROW_CHUNKS = 12;     // float4 per row
+constexpr int SH_LDS_STRIDE = 13;     // float4 per row in LDS
+constexpr int SH_WAVE_LDS_F4 = 64 * SH_LDS_STRIDE;
+
+// Orders one wave's LDS writes before its later LDS reads (other lanes' data).
+// The LDS unit serves a wave's instructions in order, so no hardware wait is
+// needed; the wavefront-scope fences keep the compiler from moving accesses
+// across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// global -> LDS for the rows whose bit is set in `rows`; `g` points at row 0 of the wave.
+__device__ __forceinline__ void sh_rows_load(const float* __restrict__ g, float4* lds, uint64_t rows, int nrows, int lane) {
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+#pragma unroll
+    for (int it = 0; it < SH_ROW_CHUNKS; ++it) {
+        const int i = it * 64 + lane;          // chunk index inside the wave's 768 chunks
+        const int r = i / SH_ROW_CHUNKS, c = i - r * SH_ROW_CHUNKS;
+        if (r < nrows && ((rows >> r) & 1ull)) lds[r * SH_LDS_STRIDE + c] = g4[i];
+    }
+}
+
+// LDS -> global for rows [0, nrows).
+__device__ __forceinline__ void sh_rows_store(float* __restrict__ g, const float4* lds, int nrows, int lane) {
+    float4* g4 = reinterpret_cast<float4*>(g);
+#pragma unroll
+    for (int it = 0; it < SH_ROW_CHUNKS; ++it) {
+        const int i = it * 64 + lane;
+        const int r = i / SH_ROW_CHUNKS, c = i - r * SH_ROW_CHUNKS;
+        if (r < nrows) g4[i] = lds[r * SH_LDS_STRIDE + c];
+    }
+}
+
+// One lane's row between LDS and registers.
+__device__ __forceinline__ void sh_row_get(const float4* lds, int lane, float (&v)[SH_ROW_F]) {
+#pragma unroll
+    for (int c = 0; c < SH_ROW_CHUNKS; ++c) {
+        const float4 q = lds[lane * SH_LDS_STRIDE + c];
+        v[4 * c] = q.x; v[4 * c + 1] = q.y; v[4 * c + 2] = q.z; v[4 * c + 3] = q.w;
+    }
+}
+__device__ __forceinline__ void sh_row_put(float4* lds, int lane, const float (&v)[SH_ROW_F]) {
+#pragma unroll
+    for (int c = 0; c < SH_ROW_CHUNKS; ++c)
+        lds[lane * SH_LDS_STRIDE + c] = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+}
+
 // ------------------------------------------------------------------ buffers
 // One Gaussian's screen-space record, written by the forward preprocess and
 // gathered (one 64-byte line half) by both render kernels.
