@@ -91,11 +91,6 @@ __global__ void __launch_bounds__(256) sh_bwd_kernel(const PreBwdArgs a) {
     }
 }
 
-struct ShRegs {
-    const float* v;
-    __device__ __forceinline__ V3 operator()(int k) const { return v3(v[3 * k], v[3 * k + 1], v[3 * k + 2]); }
-};
-
 // Everything for one rendered Gaussian.  LDS_SH: its SH row is in `lds` and its
 // dL/dSH row is left there; otherwise sh_bwd_kernel did the SH part.
 template <bool LDS_SH>
@@ -105,6 +100,34 @@ __device__ __forceinline__ void pre_bwd_rendered(const PreBwdArgs& a, size_t i, 
     const float4 g0 = gq[0], g1 = gq[1], g2 = gq[2], g3 = gq[3];
     const V3 mean = v3(a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]);
 
+    // SH first: its 96 live registers are released before the covariance chain starts.
+    V3 dmean = v3(0, 0, 0);
+    if (LDS_SH) {
+        float shv[SH_ROW_F];
+        sh_row_get(lds, lane, shv);
+        const uint8_t cl = a.clamped[i];
+        V3 gcol = v3(g1.z, g1.w, g2.x);
+        gcol.x *= (cl & 1) ? 0 : 1;
+        gcol.y *= (cl & 2) ? 0 : 1;
+        gcol.z *= (cl & 4) ? 0 : 1;
+        // The row is in registers now; dL/dSH overwrites it in LDS coefficient by
+        // coefficient (only this lane touches its row between the two wave-wide copies).
+        float* row = reinterpret_cast<float*>(lds + lane * SH_LDS_STRIDE);
+        const int ncoef = (c.sh_degree + 1) * (c.sh_degree + 1);
+#pragma unroll
+        for (int ch = 0; ch < SH_ROW_CHUNKS; ++ch)
+            if (4 * ch + 3 >= 3 * ncoef) lds[lane * SH_LDS_STRIDE + ch] = make_float4(0, 0, 0, 0);
+        auto out = [row](int k, V3 v) {
+            row[3 * k] = v.x;
+            row[3 * k + 1] = v.y;
+            row[3 * k + 2] = v.z;
+        };
+        ShRegs sh = {shv};
+        dmean = sh_to_rgb_bwd(c.sh_degree, mean, v3(c.campos[0], c.campos[1], c.campos[2]), gcol, sh, out);
+    } else if (a.shs) {  // direction term, left there by sh_bwd_kernel
+        dmean = v3(a.dL_dmeans3D[3 * i], a.dL_dmeans3D[3 * i + 1], a.dL_dmeans3D[3 * i + 2]);
+    }
+    if (LDS_SH) wave_lds_sync();
     float cov6[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) cov6[k] = a.cov3D[6 * i + k];
@@ -112,30 +135,9 @@ __device__ __forceinline__ void pre_bwd_rendered(const PreBwdArgs& a, size_t i, 
     const float dinv = g2.y;
     float dcov6[6];
     const V3 dconic = v3(g0.z, g0.w, g1.x);
-    V3 dmean = cov2d_bwd(c, mean, cov6, a.opacities[i], dconic, &dop, a.has_invdepth ? &dinv : nullptr, dcov6);
+    dmean = add(dmean, cov2d_bwd(c, mean, cov6, a.opacities[i], dconic, &dop, a.has_invdepth ? &dinv : nullptr, dcov6));
     dmean = add(dmean, mean2d_bwd(mean, c.proj, g0.x, g0.y));
 
-    if (LDS_SH) {
-        float shv[SH_ROW_F], dshv[SH_ROW_F];
-        sh_row_get(lds, lane, shv);
-        const uint8_t cl = a.clamped[i];
-        V3 gcol = v3(g1.z, g1.w, g2.x);
-        gcol.x *= (cl & 1) ? 0 : 1;
-        gcol.y *= (cl & 2) ? 0 : 1;
-        gcol.z *= (cl & 4) ? 0 : 1;
-#pragma unroll
-        for (int k = 0; k < SH_ROW_F; ++k) dshv[k] = 0.f;
-        auto out = [&dshv](int k, V3 v) {
-            dshv[3 * k] = v.x;
-            dshv[3 * k + 1] = v.y;
-            dshv[3 * k + 2] = v.z;
-        };
-        ShRegs sh = {shv};
-        dmean = add(dmean, sh_to_rgb_bwd(c.sh_degree, mean, v3(c.campos[0], c.campos[1], c.campos[2]), gcol, sh, out));
-        sh_row_put(lds, lane, dshv);  // only this lane touches its row between the two wave-wide copies
-    } else if (a.shs) {  // direction term, left there by sh_bwd_kernel
-        dmean = add(dmean, v3(a.dL_dmeans3D[3 * i], a.dL_dmeans3D[3 * i + 1], a.dL_dmeans3D[3 * i + 2]));
-    }
     if (a.scales) {
         const V3 sc = v3(a.scales[3 * i], a.scales[3 * i + 1], a.scales[3 * i + 2]);
         const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[i];
@@ -183,10 +185,13 @@ __device__ __forceinline__ void pre_bwd_unrendered(const PreBwdArgs& a, size_t i
     if (a.DIM == 4) reinterpret_cast<float4*>(a.dL_dreps)[i] = make_float4(0, 0, 0, 0);
 }
 
+#ifndef PRE_BWD_WAVES
+#define PRE_BWD_WAVES 2
+#endif
 // LDS_SH: shs is [P,16,3] and is handled inside this kernel through LDS;
 // otherwise the SH part was done by sh_bwd_kernel (or there are no SHs).
 template <bool LDS_SH>
-__global__ void __launch_bounds__(256) preprocess_bwd_kernel(const PreBwdArgs a) {
+__global__ void __launch_bounds__(256, PRE_BWD_WAVES) preprocess_bwd_kernel(const PreBwdArgs a) {
     __shared__ float4 s_sh[LDS_SH ? 4 * SH_WAVE_LDS_F4 : 1];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;

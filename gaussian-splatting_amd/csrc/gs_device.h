@@ -169,6 +169,12 @@ __device__ __forceinline__ void sh_row_put(float4* lds, int lane, const float (&
         lds[lane * SH_LDS_STRIDE + c] = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
 }
 
+// Coefficient accessor over a row held in registers (for sh_to_rgb / sh_to_rgb_bwd).
+struct ShRegs {
+    const float* v;
+    __device__ __forceinline__ V3 operator()(int k) const { return v3(v[3 * k], v[3 * k + 1], v[3 * k + 2]); }
+};
+
 // ------------------------------------------------------------------ buffers
 // One Gaussian's screen-space record, written by the forward preprocess and
 // gathered (one 64-byte line half) by both render kernels.
