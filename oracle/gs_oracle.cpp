@@ -574,8 +574,12 @@ void gso_expf(const float* x, float* y, int64_t n) {
 
 // ------------------------------------------------------------------ simple-knn
 
-void gso_dist2(int P, const float* pts, float* mean_dists) {
+// stride > 1: only every stride-th point of the Morton order is searched (the
+// same search, for checking large inputs in bounded time); the others get -1.
+void gso_dist2_strided(int P, const float* pts, float* mean_dists, int stride) {
     if (P <= 0) return;
+    if (stride > 1)
+        for (int i = 0; i < P; ++i) mean_dists[i] = -1.0f;
     auto pt = [&](uint32_t i) { return v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]); };
     V3 mn = v3(0, 0, 0), mx = v3(0, 0, 0);  // reduce seeded with the origin (simple_knn.cu:192-200)
     for (int i = 0; i < P; ++i) {
@@ -604,6 +608,7 @@ void gso_dist2(int P, const float* pts, float* mean_dists) {
     }
 #pragma omp parallel for schedule(dynamic, 256)
     for (int i = 0; i < P; ++i) {
+        if (stride > 1 && i % stride) continue;
         const V3 p = pt(order[i]);
         float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
         for (int j = std::max(0, i - 3); j <= std::min(P - 1, i + 3); ++j) {
@@ -623,6 +628,8 @@ void gso_dist2(int P, const float* pts, float* mean_dists) {
         mean_dists[order[i]] = (best[0] + best[1] + best[2]) / 3.0f;
     }
 }
+
+void gso_dist2(int P, const float* pts, float* mean_dists) { gso_dist2_strided(P, pts, mean_dists, 1); }
 
 // ------------------------------------------------------------------ fused-ssim
 

@@ -77,6 +77,7 @@ def lib():
         _lib.gso_expf.argtypes = [_fp, _fp, C.c_int64]
         _lib.gso_sh_eval.argtypes = [C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _bp]
         _lib.gso_dist2.argtypes = [C.c_int, _fp, _fp]
+        _lib.gso_dist2_strided.argtypes = [C.c_int, _fp, _fp, C.c_int]
         _lib.gso_ssim_fwd.argtypes = [C.c_int] * 4 + [C.c_float] * 2 + [_fp] * 6
         _lib.gso_ssim_bwd.argtypes = [C.c_int] * 4 + [_fp] * 7
         _lib.gso_num_threads.restype = C.c_int
@@ -269,10 +270,11 @@ def sh_eval(deg, pos, campos, shs):
     return rgb, cl
 
 
-def dist2(points):
+def dist2(points, stride=1):
+    """stride > 1: only every stride-th point of the Morton order is searched, the rest are -1."""
     p = _c(points)
     out = np.zeros(p.shape[0], np.float32)
-    lib().gso_dist2(p.shape[0], _f(p), _f(out))
+    lib().gso_dist2_strided(p.shape[0], _f(p), _f(out), int(stride))
     return out
 
 

@@ -1,0 +1,133 @@
+"""GPU parity at the full sizes of the benchmark configurations.
+
+  C2  2.5 M Gaussians, 1920x1080, render only      full comparison with the CPU checker
+  C3  6 M Gaussians, 1297x840, antialiasing,        full comparison, forward and backward,
+      forward + fused-ssim + backward               plus the ssim kernels on the rendered image
+  C5  20 M Gaussians, 3840x2160 render and          size-independent properties (sortedness, ranges,
+      distCUDA2 over the 20 M points                permutation, counts), knn exact on a strided
+                                                    sample of query points through the CPU checker
+
+Bars as everywhere: integers bit-exact, per-pixel floats 1e-5 absolute,
+accumulated floats and gradients 1e-4 relative.  Each test prints how long the
+CPU checker took; the sizes are chosen so that the file finishes in a few
+minutes on the 16 host cores of a one-GPU box.
+"""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from gpu_util import read_internals, rel_err, run_forward_raw, scene_to_torch
+from test_gpu_rasterizer import ABS_TOL, REL_TOL, _check_forward, _grads_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c2_render_2p5M_1080p(oracle):
+    sc = synth.street_scene(2_500_000, 1920, 1080, seed=2)
+    t0 = time.time()
+    f, out, rs, ten, _ = _check_forward(oracle, sc, False, (0.0, 0.0, 0.0))
+    print(f"C2: R={f.R}, forward on both sides + compare {time.time() - t0:.1f}s")
+    assert f.R > 5_000_000
+
+
+def test_c3_train_step_6M_1297x840(oracle):
+    sc = synth.street_scene(6_000_000, 1297, 840, seed=3)
+    t0 = time.time()
+    f, out, rs, ten, kw_g = _check_forward(oracle, sc, True, (0.0, 0.0, 0.0))
+    t1 = time.time()
+    H, W = rs.image_height, rs.image_width
+    # the gradient a training step sends back: L1 + (1 - ssim) against a fixed image, reps regulariser
+    from fused_ssim import fused_ssim
+    gt = torch.rand((3, H, W), device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(5))
+    img = out["color"].clone().requires_grad_(True)
+    rep = out["out_reps"].clone().requires_grad_(True)
+    ic = img.clamp(0, 1)
+    loss = 0.8 * (ic - gt).abs().mean() + 0.2 * (1 - fused_ssim(ic.unsqueeze(0), gt.unsqueeze(0)))
+    loss = loss + 0.01 * (rep - 10.0).abs().mean()
+    loss.backward()
+    gc, gr = img.grad.contiguous(), rep.grad.contiguous()
+    # ssim value against the CPU checker on this image
+    icn, gtn = ic.detach().cpu().numpy()[None], gt.cpu().numpy()[None]
+    m, d1, d2, d3 = oracle.ssim_fwd(icn, gtn)
+    val = fused_ssim(ic.detach().unsqueeze(0), gt.unsqueeze(0), train=False)
+    assert abs(float(val) - float(m.astype(np.float64).mean())) <= 1e-5
+    ref = f.backward(gc.cpu().numpy(), None, gr.cpu().numpy())
+    t2 = time.time()
+    got = _grads_gpu(rs, ten, gc, None, gr, kw_g, out)
+    torch.cuda.synchronize()
+    for k in got:
+        r = ref[k].reshape(got[k].shape)
+        assert np.isfinite(got[k]).all(), k
+        assert rel_err(got[k], r) <= REL_TOL, (k, rel_err(got[k], r))
+    print(f"C3: R={f.R}, forward {t1 - t0:.1f}s, backward {t2 - t1:.1f}s")
+
+
+def test_c5_render_20M_4k_properties():
+    P, W, H = 20_000_000, 3840, 2160
+    sc = synth.street_scene(P, W, H, seed=5)
+    rs, ten = scene_to_torch(sc, antialiasing=True, debug=False)
+    out = run_forward_raw(rs, ten)
+    torch.cuda.synchronize()
+    R = out["num_rendered"]
+    it = read_internals(out, P, W, H)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    radii = out["radii"].cpu().numpy()
+    tiles = it["bin"][:, 3].astype(np.int64)
+    # the instance count is the sum of the tile rectangles, culled Gaussians have none
+    assert int(tiles.sum()) == R and R > 50_000_000
+    assert np.all((tiles > 0) == (radii > 0))
+    keys, pl = it["keys"], it["point_list"]
+    tile_of = (keys >> np.uint64(32)).astype(np.int64)
+    assert np.all(keys[:-1] <= keys[1:])                               # sorted by (tile, depth)
+    assert tile_of.max() < gx * gy
+    assert np.array_equal(np.bincount(pl, minlength=P).astype(np.int64), tiles)   # every instance exactly once
+    # the depth half of a key is the f32 bits of its Gaussian's view depth
+    depths = out["out_depths"].cpu().numpy().view(np.uint32)
+    assert np.array_equal((keys & np.uint64(0xFFFFFFFF)).astype(np.uint32), depths[pl])
+    # stable: equal keys keep the emission order (ascending Gaussian index inside one tile)
+    same = keys[:-1] == keys[1:]
+    assert np.all(pl[:-1][same] < pl[1:][same])
+    # ranges partition the sorted list by tile
+    cnt = np.bincount(tile_of, minlength=gx * gy)
+    rng_ = it["ranges"].astype(np.int64)
+    nz = cnt > 0
+    assert np.array_equal((rng_[:, 1] - rng_[:, 0])[nz], cnt[nz])
+    starts = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    assert np.array_equal(rng_[nz, 0], starts[nz])
+    # per pixel: no more contributors than the tile's list, transmittance and colour in range
+    ncontrib = it["n_contrib"].reshape(H, W).astype(np.int64)
+    per_tile = cnt.reshape(gy, gx)
+    lim = np.repeat(np.repeat(per_tile, 16, axis=0), 16, axis=1)[:H, :W]
+    assert np.all(ncontrib <= lim)
+    T = it["final_T"]
+    assert np.all((T >= 0) & (T <= 1))
+    col = out["color"].cpu().numpy()
+    assert np.isfinite(col).all() and col.min() >= 0
+    # the fork's accum_alpha output is the final transmittance itself (forward.cu:478-479)
+    assert np.array_equal(out["accum_alpha"].cpu().numpy().reshape(-1), T)
+    # last contributor: -1 exactly where nothing contributed
+    last = out["last_contr_gauss"].cpu().numpy().reshape(H, W)
+    assert np.all((last >= 0) == (ncontrib > 0))
+    # every tested pair was counted once: the counts cannot exceed the pixels of the tiles a Gaussian touches
+    gcnt = out["gauss_count"].cpu().numpy().astype(np.int64)
+    assert np.all(gcnt >= 0) and np.all(gcnt <= tiles * 256)
+    assert np.all(gcnt[radii == 0] == 0)
+
+
+def test_c5_dist2_20M_points(oracle):
+    from simple_knn._C import distCUDA2
+    P = 20_000_000
+    sc = synth.street_scene(P, 3840, 2160, seed=5)
+    pts = np.ascontiguousarray(sc["means3D"], np.float32)
+    del sc
+    got = distCUDA2(torch.tensor(pts, device="cuda:0")).cpu().numpy()
+    assert got.shape == (P,) and np.isfinite(got).all() and np.all(got >= 0)
+    t0 = time.time()
+    ref = oracle.dist2(pts, stride=97)     # the same search for every 97th point of the Morton order
+    print(f"C5 knn: CPU checker {time.time() - t0:.1f}s")
+    sel = ref >= 0
+    assert sel.sum() >= P // 97
+    assert np.array_equal(got[sel], ref[sel])
