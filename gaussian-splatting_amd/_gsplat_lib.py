@@ -22,7 +22,7 @@ class GsrScene(C.Structure):
                                    "cov3D_precomp", "reps", "viewmatrix", "projmatrix", "campos")] + \
                [(n, C.c_float) for n in ("scale_modifier", "tanfovx", "tanfovy")] + \
                [(n, C.c_int) for n in ("prefiltered", "antialiasing", "debug")] + \
-               [("profile_events", C.POINTER(C.c_void_p))]
+               [("profile_events", C.POINTER(C.c_void_p)), ("raw_params", C.c_int), ("shs_rest", _vp)]
 
 
 class GsrForwardOut(C.Structure):
@@ -34,7 +34,8 @@ class GsrForwardOut(C.Structure):
 class GsrBackwardIO(C.Structure):
     _fields_ = [(n, _vp) for n in ("dL_dout_color", "dL_dout_invdepth", "dL_dout_reps", "dL_dmeans2D", "dL_dcolors",
                                    "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations",
-                                   "dL_dreps", "work")] + [("work_bytes", C.c_size_t)]
+                                   "dL_dreps", "work")] + \
+               [("work_bytes", C.c_size_t), ("dL_dsh_rest", _vp), ("accumulate", C.c_int)]
 
 
 class GsrLayout(C.Structure):

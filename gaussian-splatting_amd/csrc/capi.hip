@@ -34,6 +34,8 @@ int check_scene(const GsrScene* s) {
     if (!sr && (s->scales || s->rotations)) return GSR_ERR_ARG;
     if (s->DIM > 0 && !s->reps) return GSR_ERR_ARG;
     if (s->shs && (s->M <= 0 || (s->D + 1) * (s->D + 1) > s->M || s->D < 0 || s->D > 3)) return GSR_ERR_ARG;
+    if (s->shs_rest && (!s->shs || s->M < 2)) return GSR_ERR_ARG;
+    if (s->raw_params && !sr) return GSR_ERR_ARG;  // raw mode activates scales and rotations
     if (s->W > 65535 * TILE_X || s->H > 65535 * TILE_Y) return GSR_ERR_ARG;
     return GSR_OK;
 }
@@ -144,6 +146,7 @@ int gsr_backward(const GsrScene* s, const int* radii, const void* geom_buffer, c
     if (!radii || !geom_buffer || !image_buffer || !io->dL_dout_color || !io->work) return GSR_ERR_ARG;
     if (!io->dL_dmeans2D || !io->dL_dcolors || !io->dL_dopacity || !io->dL_dmeans3D || !io->dL_dcov3D) return GSR_ERR_ARG;
     if (s->M > 0 && s->shs && !io->dL_dsh) return GSR_ERR_ARG;
+    if (s->shs_rest && !io->dL_dsh_rest) return GSR_ERR_ARG;
     if (s->scales && (!io->dL_dscales || !io->dL_drotations)) return GSR_ERR_ARG;
     if (s->DIM > 0 && (!io->dL_dreps || !io->dL_dout_reps)) return GSR_ERR_ARG;
     if (io->work_bytes < gsr_backward_work_bytes(s->P)) return GSR_ERR_BUFFER;

@@ -22,6 +22,8 @@ struct PreArgs {
     const float* rotations;
     const float* cov3D_precomp;
     const float* reps;
+    int raw;                // opacities / scales / rotations are pre-activation values
+    const float* shs_rest;  // SH split into shs [P,1,3] and shs_rest [P,M-1,3]
     CamPtrs cam;
     int* radii;
     float* out_depths;
@@ -31,11 +33,6 @@ struct PreArgs {
     float2* gstat;
     uint8_t* clamped;
     uint32_t* block_sums;
-};
-
-struct ShGlobal {
-    const float* p;
-    __device__ __forceinline__ V3 operator()(int k) const { return v3(p[3 * k], p[3 * k + 1], p[3 * k + 2]); }
 };
 
 __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs a) {
@@ -54,18 +51,32 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs
 #pragma unroll
                 for (int i = 0; i < 6; ++i) cov6[i] = a.cov3D_precomp[6 * (size_t)idx + i];
             } else {
-                const V3 sc = v3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
+                V3 sc = v3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
                 const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[idx];
-                const V4 q = {q4.x, q4.y, q4.z, q4.w};
+                V4 q = {q4.x, q4.y, q4.z, q4.w};
+                if (a.raw) {
+                    float dn;
+                    sc = act_exp3(sc);
+                    q = act_normalize4(q, &dn);
+                }
                 cov3d_from_scale_rot(sc, c.scale_modifier, q, cov6);
             }
+            float opac = a.opacities[idx];
+            if (a.raw) opac = act_sigmoid(opac);
             Splat sp;
-            if (project_splat(c, p, cov6, a.opacities[idx], depth, &sp)) {
+            if (project_splat(c, p, cov6, opac, depth, &sp)) {
                 V3 col;
                 if (a.colors_precomp) {
                     col = v3(a.colors_precomp[3 * idx], a.colors_precomp[3 * idx + 1], a.colors_precomp[3 * idx + 2]);
                 } else {
-                    ShGlobal sh = {a.shs + (size_t)idx * a.M * 3};
+                    ShPtr sh;
+                    if (a.shs_rest) {
+                        sh.dc = a.shs + 3 * (size_t)idx;
+                        sh.rest = a.shs_rest + (size_t)idx * (a.M - 1) * 3;
+                    } else {
+                        sh.dc = a.shs + (size_t)idx * a.M * 3;
+                        sh.rest = sh.dc + 3;
+                    }
                     col = sh_to_rgb(c.sh_degree, p, v3(c.campos[0], c.campos[1], c.campos[2]), sh);
                     a.clamped[idx] = (uint8_t)((col.x < 0 ? 1 : 0) | (col.y < 0 ? 2 : 0) | (col.z < 0 ? 4 : 0));
                     col = v3(fmax_(col.x, 0.0f), fmax_(col.y, 0.0f), fmax_(col.z, 0.0f));
@@ -232,6 +243,7 @@ hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, cons
     a.mod = s.scale_modifier; a.tanx = s.tanfovx; a.tany = s.tanfovy; a.aa = s.antialiasing;
     a.means3D = s.means3D; a.shs = s.shs; a.colors_precomp = s.colors_precomp; a.opacities = s.opacities;
     a.scales = s.scales; a.rotations = s.rotations; a.cov3D_precomp = s.cov3D_precomp; a.reps = s.reps;
+    a.raw = s.raw_params; a.shs_rest = s.shs_rest;
     a.cam.view = s.viewmatrix; a.cam.proj = s.projmatrix; a.cam.campos = s.campos;
     a.radii = o.radii; a.out_depths = o.out_depths;
     a.rec = g.rec; a.cov3D = g.cov3D; a.bin = g.bin; a.gstat = g.gstat; a.clamped = g.clamped;

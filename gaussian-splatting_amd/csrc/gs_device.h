@@ -155,6 +155,20 @@ __device__ __forceinline__ void sh_rows_store(float* __restrict__ g, const float
     }
 }
 
+// global += LDS for the rows whose bit is set in `rows`.
+__device__ __forceinline__ void sh_rows_add(float* __restrict__ g, const float4* lds, uint64_t rows, int nrows, int lane) {
+    float4* g4 = reinterpret_cast<float4*>(g);
+#pragma unroll
+    for (int it = 0; it < SH_ROW_CHUNKS; ++it) {
+        const int i = it * 64 + lane;
+        const int r = i / SH_ROW_CHUNKS, c = i - r * SH_ROW_CHUNKS;
+        if (r < nrows && ((rows >> r) & 1ull)) {
+            const float4 o = g4[i], v = lds[r * SH_LDS_STRIDE + c];
+            g4[i] = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+        }
+    }
+}
+
 // One lane's row between LDS and registers.
 __device__ __forceinline__ void sh_row_get(const float4* lds, int lane, float (&v)[SH_ROW_F]) {
 #pragma unroll

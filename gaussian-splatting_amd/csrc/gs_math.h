@@ -328,54 +328,42 @@ GS_HD V3 sh_to_rgb_bwd(int deg, V3 pos, V3 campos, V3 g, SH sh, OUT out) {
     return dnormvdv(dir_orig, ddir);
 }
 
-// One SH basis function and its gradient w.r.t. the (unit) direction, in the
-// form the backward uses them (backward.cu:50-125): colour = sum_k B_k(dir) sh_k.
-GS_HD void sh_basis_grad(int k, float x, float y, float z, float* B, float* Bx, float* By, float* Bz) {
-    const float xx = x * x, yy = y * y, zz = z * z;
-    const float xy = x * y, yz = y * z, xz = x * z;
-    float b = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
-    switch (k) {
-        case 0: b = GS_SH_C0; break;
-        case 1: b = -GS_SH_C1 * y; by = -GS_SH_C1; break;
-        case 2: b = GS_SH_C1 * z; bz = GS_SH_C1; break;
-        case 3: b = -GS_SH_C1 * x; bx = -GS_SH_C1; break;
-        case 4: b = GS_SH_C2_0 * xy; bx = GS_SH_C2_0 * y; by = GS_SH_C2_0 * x; break;
-        case 5: b = GS_SH_C2_1 * yz; by = GS_SH_C2_1 * z; bz = GS_SH_C2_1 * y; break;
-        case 6:
-            b = GS_SH_C2_2 * (2.f * zz - xx - yy);
-            bx = GS_SH_C2_2 * 2.f * -x; by = GS_SH_C2_2 * 2.f * -y; bz = GS_SH_C2_2 * 2.f * 2.f * z;
-            break;
-        case 7: b = GS_SH_C2_3 * xz; bx = GS_SH_C2_3 * z; bz = GS_SH_C2_3 * x; break;
-        case 8: b = GS_SH_C2_4 * (xx - yy); bx = GS_SH_C2_4 * 2.f * x; by = GS_SH_C2_4 * 2.f * -y; break;
-        case 9:
-            b = GS_SH_C3_0 * y * (3.f * xx - yy);
-            bx = GS_SH_C3_0 * 3.f * 2.f * xy; by = GS_SH_C3_0 * 3.f * (xx - yy);
-            break;
-        case 10: b = GS_SH_C3_1 * xy * z; bx = GS_SH_C3_1 * yz; by = GS_SH_C3_1 * xz; bz = GS_SH_C3_1 * xy; break;
-        case 11:
-            b = GS_SH_C3_2 * y * (4.f * zz - xx - yy);
-            bx = GS_SH_C3_2 * -2.f * xy; by = GS_SH_C3_2 * (-3.f * yy + 4.f * zz - xx); bz = GS_SH_C3_2 * 4.f * 2.f * yz;
-            break;
-        case 12:
-            b = GS_SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
-            bx = GS_SH_C3_3 * -3.f * 2.f * xz; by = GS_SH_C3_3 * -3.f * 2.f * yz;
-            bz = GS_SH_C3_3 * 3.f * (2.f * zz - xx - yy);
-            break;
-        case 13:
-            b = GS_SH_C3_4 * x * (4.f * zz - xx - yy);
-            bx = GS_SH_C3_4 * (-3.f * xx + 4.f * zz - yy); by = GS_SH_C3_4 * -2.f * xy; bz = GS_SH_C3_4 * 4.f * 2.f * xz;
-            break;
-        case 14:
-            b = GS_SH_C3_5 * z * (xx - yy);
-            bx = GS_SH_C3_5 * 2.f * xz; by = GS_SH_C3_5 * -2.f * yz; bz = GS_SH_C3_5 * (xx - yy);
-            break;
-        case 15:
-            b = GS_SH_C3_6 * x * (xx - 3.f * yy);
-            bx = GS_SH_C3_6 * 3.f * (xx - yy); by = GS_SH_C3_6 * -3.f * 2.f * xy;
-            break;
-        default: break;
+// SH coefficient k of one Gaussian when the DC term and the other
+// coefficients may live in two tensors (scene/gaussian_model.py:487-498 keeps
+// _features_dc [P,1,3] and _features_rest [P,M-1,3]); for one [P,M,3] tensor
+// rest = dc + 3.
+struct ShPtr {
+    const float* dc;
+    const float* rest;
+    GS_HD V3 operator()(int k) const {
+        const float* p = k == 0 ? dc : rest + 3 * (k - 1);
+        return v3(p[0], p[1], p[2]);
     }
-    *B = b; *Bx = bx; *By = by; *Bz = bz;
+};
+
+// ---------------------------------------------------------------- activations
+// Raw-parameter mode folds the activations the model applies before every
+// render (scene/gaussian_model.py:41-53, 470-502) into the kernels:
+// scaling = exp, opacity = sigmoid, rotation = x / max(|x|, 1e-12).
+
+GS_HD float act_sigmoid(float x) { return 1.0f / (1.0f + gs_expf(-x)); }
+GS_HD float act_sigmoid_bwd(float y, float g) { return g * ((1.0f - y) * y); }
+GS_HD V3 act_exp3(V3 x) { return v3(gs_expf(x.x), gs_expf(x.y), gs_expf(x.z)); }
+GS_HD V3 act_exp3_bwd(V3 y, V3 g) { return v3(g.x * y.x, g.y * y.y, g.z * y.z); }
+
+GS_HD V4 act_normalize4(V4 q, float* denom) {
+    const float n = sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+    const float d = fmax_(n, 1e-12f);
+    *denom = d;
+    V4 r = {q.x / d, q.y / d, q.z / d, q.w / d};
+    return r;
+}
+// y = act_normalize4(x), g = dL/dy.  Below the clamp the map is x / 1e-12 (linear).
+GS_HD V4 act_normalize4_bwd(V4 y, float denom, V4 g) {
+    float t = ((y.x * g.x + y.y * g.y) + y.z * g.z) + y.w * g.w;
+    if (!(denom > 1e-12f)) t = 0.0f;
+    V4 r = {(g.x - y.x * t) / denom, (g.y - y.y * t) / denom, (g.z - y.z * t) / denom, (g.w - y.w * t) / denom};
+    return r;
 }
 
 // ---------------------------------------------------------------- covariance

@@ -13,19 +13,23 @@ SUPPORTED_DIMS = (0, 4)
 
 
 def _scene(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
-           tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, antialiasing, debug, reps, keep):
+           tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, antialiasing, debug, reps, keep,
+           sh_rest=None, raw=False):
     dev = means3D.device
     P = means3D.size(0)
     s = GsrScene()
     t = dict(bg=bg, means3D=means3D, shs=sh, colors_precomp=colors, opacities=opacity, scales=scales,
              rotations=rotations, cov3D_precomp=cov3D_precomp, reps=reps, viewmatrix=viewmatrix,
-             projmatrix=projmatrix, campos=campos)
+             projmatrix=projmatrix, campos=campos, shs_rest=sh_rest)
     for name, ten in t.items():
         c = dev_f32(ten, dev, name)
         keep.append(c)
         setattr(s, name, ptr(c))
     s.P, s.D, s.W, s.H = P, int(degree), int(W), int(H)
     s.M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
+    if sh_rest is not None and sh_rest.numel() != 0:
+        s.M += int(sh_rest.size(1))
+    s.raw_params = int(bool(raw))
     s.DIM = int(reps.size(1)) if (reps is not None and reps.numel() != 0) else 0
     s.scale_modifier, s.tanfovx, s.tanfovy = float(scale_modifier), float(tan_fovx), float(tan_fovy)
     s.prefiltered, s.antialiasing, s.debug = int(bool(prefiltered)), int(bool(antialiasing)), int(bool(debug))
@@ -46,10 +50,15 @@ def _check_shapes(means3D, reps):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, antialiasing, debug, reps=None):
+                        prefiltered, antialiasing, debug, reps=None, sh_rest=None, raw_params=False):
     """rasterize_points.cu:35-206.  Returns (num_rendered, color, radii,
     geomBuffer, binningBuffer, imgBuffer, invdepth, accum_alpha, gauss_sum,
-    gauss_count, last_contr_gauss, out_depths, out_reps)."""
+    gauss_count, last_contr_gauss, out_depths, out_reps).
+
+    Beyond the reference: `sh_rest` (then `sh` is the [P,1,3] DC tensor and
+    `sh_rest` the [P,M-1,3] remainder, uncatenated) and `raw_params` (opacity
+    logits, log-scales and unnormalised rotations; the kernels apply the
+    activations of scene/gaussian_model.py:41-53)."""
     _check_shapes(means3D, reps)
     if not means3D.is_cuda:
         raise RuntimeError("means3D must be a GPU tensor (there is no CPU path)")
@@ -60,7 +69,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     with torch.cuda.device(dev):
         s = _scene(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                    projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, antialiasing, debug, reps,
-                   keep)
+                   keep, sh_rest=sh_rest, raw=raw_params)
         DIM = s.DIM
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -96,10 +105,16 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_invdepth, dL_dout_reps, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                 imageBuffer, antialiasing, debug, reps=None):
+                                 imageBuffer, antialiasing, debug, reps=None, sh_rest=None, raw_params=False,
+                                 into=None, accumulate=False):
     """rasterize_points.cu:208-345.  Returns (dL_dmeans2D, dL_dcolors,
     dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations,
-    dL_dreps)."""
+    dL_dreps), plus dL_dsh_rest as a tenth element when `sh_rest` is given.
+
+    Beyond the reference: `sh_rest` / `raw_params` as in the forward;
+    `into` = dict of preallocated gradient tensors (keys means3D, opacity, sh,
+    sh_rest, scales, rotations, reps) that the kernels write directly, adding
+    to their contents when `accumulate` is set."""
     L = lib()
     dev = means3D.device
     P = means3D.size(0)
@@ -108,16 +123,32 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
     with torch.cuda.device(dev):
         s = _scene(background, means3D, colors, opacities, scales, rotations, scale_modifier, cov3D_precomp,
                    viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, False, antialiasing, debug,
-                   reps, keep)
+                   reps, keep, sh_rest=sh_rest, raw=raw_params)
         M, DIM = s.M, s.DIM
+        split = sh_rest is not None and sh_rest.numel() != 0
+        into = into or {}
+        if accumulate and not all(k in into for k in ("means3D", "opacity", "sh", "scales", "rotations")):
+            raise RuntimeError("accumulate needs the gradient tensors to add into")
         f32 = dict(dtype=torch.float32, device=dev)
         has_sr = scales is not None and scales.numel() != 0
         e = torch.empty
-        dL_dmeans3D, dL_dmeans2D, dL_dcolors = e((P, 3), **f32), e((P, 3), **f32), e((P, 3), **f32)
-        dL_dopacity, dL_dcov3D, dL_dsh = e((P, 1), **f32), e((P, 6), **f32), e((P, M, 3), **f32)
-        dL_dscales = e((P, 3), **f32) if has_sr else torch.zeros((P, 3), **f32)
-        dL_drotations = e((P, 4), **f32) if has_sr else torch.zeros((P, 4), **f32)
-        dL_dreps = e((P, DIM), **f32)
+
+        def buf(key, shape, fill_zero=False):
+            t = into.get(key)
+            if t is not None:
+                if t.numel() != int(torch.Size(shape).numel()) or t.dtype != torch.float32 or t.device != dev or \
+                        not t.is_contiguous():
+                    raise RuntimeError(f"gradient buffer '{key}' must be a contiguous float32 tensor of shape {shape}")
+                return t
+            return torch.zeros(shape, **f32) if fill_zero else e(shape, **f32)
+
+        dL_dmeans3D, dL_dmeans2D, dL_dcolors = buf("means3D", (P, 3)), e((P, 3), **f32), e((P, 3), **f32)
+        dL_dopacity, dL_dcov3D = buf("opacity", (P, 1)), e((P, 6), **f32)
+        dL_dsh = buf("sh", (P, 1 if split else M, 3))
+        dL_dsh_rest = buf("sh_rest", (P, M - 1, 3)) if split else None
+        dL_dscales = buf("scales", (P, 3), not has_sr)
+        dL_drotations = buf("rotations", (P, 4), not has_sr)
+        dL_dreps = buf("reps", (P, DIM))
         if P != 0:
             gc = dev_f32(dL_dout_color, dev, "dL_dout_color")
             gd = dev_f32(dL_dout_invdepth, dev, "dL_dout_invdepth")
@@ -133,9 +164,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
             io.dL_drotations = ptr(dL_drotations) if has_sr else None
             io.dL_dreps = ptr(dL_dreps)
             io.work, io.work_bytes = ptr(work), work.numel()
+            io.dL_dsh_rest = ptr(dL_dsh_rest)
+            io.accumulate = int(bool(accumulate))
             check(L.gsr_backward(C.byref(s), ptr(radii), ptr(geomBuffer), ptr(binningBuffer), ptr(imageBuffer),
                                  int(R), C.byref(io), stream_of(dev)), "rasterize_gaussians_backward")
-    return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dreps)
+    res = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dreps)
+    return res + (dL_dsh_rest,) if split else res
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

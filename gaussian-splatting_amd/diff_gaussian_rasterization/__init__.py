@@ -85,6 +85,81 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, raster_settings, reps)
 
 
+class ParamGradSink:
+    """Gradient buffers that the raw-parameter backward fills directly.
+
+    Autograd would hand back seven fresh gradient tensors per view and add them
+    into `.grad` with one elementwise kernel each (1.5 GB of parameters at 6 M
+    Gaussians).  With a sink the backward kernels write (first view of a step)
+    or add (later views) straight into persistent buffers, which are installed
+    as the parameters' `.grad`.  Call `begin_step()` before the first
+    backward of every optimiser step instead of zeroing the gradients."""
+
+    NAMES = ("means3D", "sh", "sh_rest", "opacity", "scales", "rotations", "reps")
+
+    def __init__(self, xyz, features_dc, features_rest, opacity, scaling, rotation, reps=None):
+        self.params = dict(means3D=xyz, sh=features_dc, sh_rest=features_rest, opacity=opacity, scales=scaling,
+                           rotations=rotation, reps=reps)
+        self.grads = {k: torch.zeros_like(p) for k, p in self.params.items() if p is not None and p.numel() != 0}
+        for k, g in self.grads.items():
+            self.params[k].grad = g
+        self.fresh = True
+
+    def begin_step(self):
+        """The next backward overwrites the buffers, the ones after it accumulate."""
+        self.fresh = True
+
+    def tensors(self):
+        return list(self.grads.values())
+
+
+class _RasterizeGaussiansParams(torch.autograd.Function):
+    """The same operator on the model's raw parameters: the SH tensors stay
+    split (no torch.cat, scene/gaussian_model.py:487-490) and the opacity,
+    scaling and rotation activations (scene/gaussian_model.py:41-53) run inside
+    the preprocess kernels, forward and backward."""
+
+    @staticmethod
+    def forward(ctx, xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, raster_settings, reps,
+                sink):
+        rs = raster_settings
+        empty = torch.Tensor([])
+        (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths, accum_alpha, gauss_sum,
+         gauss_count, last_contr_gauss, depths, out_reps) = _C.rasterize_gaussians(
+            rs.bg, xyz, empty, opacity, scaling, rotation, rs.scale_modifier, empty, rs.viewmatrix, rs.projmatrix,
+            rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, features_dc, rs.sh_degree, rs.campos,
+            rs.prefiltered, rs.antialiasing, rs.debug, reps, sh_rest=features_rest, raw_params=True)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.sink = sink
+        ctx.save_for_backward(xyz, scaling, rotation, radii, features_dc, features_rest, opacity, geomBuffer,
+                              binningBuffer, imgBuffer, reps)
+        return color, radii, invdepths, gauss_sum, gauss_count, out_reps
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _radii, grad_out_depth, _sum, _count, grad_out_reps):
+        rs = ctx.raster_settings
+        (xyz, scaling, rotation, radii, features_dc, features_rest, opacity, geomBuffer, binningBuffer, imgBuffer,
+         reps) = ctx.saved_tensors
+        sink = ctx.sink
+        empty = torch.Tensor([])
+        into, accumulate = None, False
+        if sink is not None:
+            into, accumulate = sink.grads, not sink.fresh
+        res = _C.rasterize_gaussians_backward(
+            rs.bg, xyz, radii, empty, opacity, scaling, rotation, rs.scale_modifier, empty, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_out_depth, grad_out_reps, features_dc,
+            rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.antialiasing,
+            rs.debug, reps, sh_rest=features_rest, raw_params=True, into=into, accumulate=accumulate)
+        g_means2D, _gc, g_opacity, g_means3D, _gcov, g_dc, g_scales, g_rot, g_reps = res[:9]
+        g_rest = res[9] if len(res) > 9 else None     # a degree-0 model has no second SH tensor
+        if sink is not None:
+            sink.fresh = False
+            return (None, g_means2D, None, None, None, None, None, None, None, None)
+        return (g_means3D, g_means2D, g_dc, g_rest, g_opacity.view_as(opacity), g_scales, g_rot, None,
+                g_reps if reps.numel() != 0 else None, None)
+
+
 class GaussianRasterizer(nn.Module):
     """__init__.py:278-340 of the reference."""
 
@@ -113,3 +188,17 @@ class GaussianRasterizer(nn.Module):
         reps = empty if reps is None else reps   # the reference requires reps; without them DIM = 0
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    self.raster_settings, reps)
+
+    def forward_params(self, xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, reps=None,
+                       grad_sink=None):
+        """Render from the model's raw parameters (`GaussianModel._xyz`,
+        `_features_dc`, `_features_rest`, `_opacity`, `_scaling`, `_rotation`,
+        `_reps`): equal to `forward(means3D=xyz, shs=cat(dc, rest),
+        opacities=sigmoid(opacity), scales=exp(scaling),
+        rotations=normalize(rotation), reps=reps)` with the activations and the
+        concatenation done inside the kernels.  Same 6-tuple result.  With a
+        `ParamGradSink` the parameter gradients are written into its buffers."""
+        features_rest = torch.Tensor([]) if features_rest is None else features_rest
+        reps = torch.Tensor([]) if reps is None else reps
+        return _RasterizeGaussiansParams.apply(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation,
+                                               self.raster_settings, reps, grad_sink)

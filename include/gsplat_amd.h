@@ -77,6 +77,15 @@ typedef struct {
     void** profile_events; /* NULL, or GSR_NUM_PROFILE_EVENTS hipEvent_t handles that the calls record on
                               `stream` around their kernels (see GsrProfileEvent); the caller reads the
                               elapsed times after synchronising */
+    /* Raw-parameter mode.  No counterpart in the reference's operator: it folds what the model does
+     * before every render (scene/gaussian_model.py:41-53, 470-502) into the kernels.
+     *   raw_params != 0: `opacities` holds logits (sigmoid is applied), `scales` log-scales (exp),
+     *                    `rotations` unnormalised quaternions (x / max(|x|, 1e-12)); the backward then
+     *                    returns gradients with respect to these raw tensors.
+     *   shs_rest != NULL: the SH coefficients come as two tensors, `shs` = [P,1,3] (DC term) and
+     *                    `shs_rest` = [P,M-1,3], instead of their concatenation (M still counts both). */
+    int raw_params;
+    const float* shs_rest;
 } GsrScene;
 
 /* Slots of GsrScene.profile_events.  Each is recorded AFTER the named step. */
@@ -132,6 +141,11 @@ typedef struct {
     float* dL_dreps;         /* device [P,DIM] or NULL iff DIM == 0 */
     void* work;              /* device, >= gsr_backward_work_bytes(P) */
     size_t work_bytes;
+    float* dL_dsh_rest;      /* device [P,M-1,3] iff scene.shs_rest != NULL (then dL_dsh is [P,1,3]) */
+    int accumulate;          /* nonzero: ADD into dL_dmeans3D, dL_dopacity, dL_dsh(+rest), dL_dscales,
+                                dL_drotations, dL_dreps instead of overwriting them (gradient accumulation
+                                over the views of a batch; Gaussians that were not rendered are then not
+                                touched).  dL_dmeans2D, dL_dcolors, dL_dcov3D are always overwritten. */
 } GsrBackwardIO;
 
 size_t gsr_geom_bytes(int P);

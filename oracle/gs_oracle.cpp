@@ -572,6 +572,41 @@ void gso_expf(const float* x, float* y, int64_t n) {
     for (int64_t i = 0; i < n; ++i) y[i] = gs_expf(x[i]);
 }
 
+// Activations the model applies before every render (scene/gaussian_model.py:41-53:
+// scaling = exp, opacity = sigmoid, rotation = F.normalize) and their backward,
+// for checking the kernels' raw-parameter mode.
+void gso_activate(int P, const float* logit, const float* logscale, const float* rot, float* opacity, float* scales,
+                  float* rotations) {
+#pragma omp parallel for
+    for (int i = 0; i < P; ++i) {
+        opacity[i] = act_sigmoid(logit[i]);
+        const V3 s = act_exp3(v3(logscale[3 * i], logscale[3 * i + 1], logscale[3 * i + 2]));
+        scales[3 * i] = s.x; scales[3 * i + 1] = s.y; scales[3 * i + 2] = s.z;
+        float dn;
+        const V4 q = {rot[4 * i], rot[4 * i + 1], rot[4 * i + 2], rot[4 * i + 3]};
+        const V4 y = act_normalize4(q, &dn);
+        rotations[4 * i] = y.x; rotations[4 * i + 1] = y.y; rotations[4 * i + 2] = y.z; rotations[4 * i + 3] = y.w;
+    }
+}
+
+// g_* are gradients w.r.t. the activated values on entry and w.r.t. the raw values on return.
+void gso_activate_bwd(int P, const float* logit, const float* logscale, const float* rot, float* g_opacity,
+                      float* g_scales, float* g_rotations) {
+#pragma omp parallel for
+    for (int i = 0; i < P; ++i) {
+        g_opacity[i] = act_sigmoid_bwd(act_sigmoid(logit[i]), g_opacity[i]);
+        const V3 s = act_exp3(v3(logscale[3 * i], logscale[3 * i + 1], logscale[3 * i + 2]));
+        const V3 gs = act_exp3_bwd(s, v3(g_scales[3 * i], g_scales[3 * i + 1], g_scales[3 * i + 2]));
+        g_scales[3 * i] = gs.x; g_scales[3 * i + 1] = gs.y; g_scales[3 * i + 2] = gs.z;
+        float dn;
+        const V4 q = {rot[4 * i], rot[4 * i + 1], rot[4 * i + 2], rot[4 * i + 3]};
+        const V4 y = act_normalize4(q, &dn);
+        const V4 g = {g_rotations[4 * i], g_rotations[4 * i + 1], g_rotations[4 * i + 2], g_rotations[4 * i + 3]};
+        const V4 r = act_normalize4_bwd(y, dn, g);
+        g_rotations[4 * i] = r.x; g_rotations[4 * i + 1] = r.y; g_rotations[4 * i + 2] = r.z; g_rotations[4 * i + 3] = r.w;
+    }
+}
+
 // ------------------------------------------------------------------ simple-knn
 
 // stride > 1: only every stride-th point of the Morton order is searched (the

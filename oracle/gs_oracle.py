@@ -76,6 +76,8 @@ def lib():
         _lib.gso_sort_pairs.argtypes = [_u64p, _up, _u64p, _up, C.c_int64, C.c_int]
         _lib.gso_expf.argtypes = [_fp, _fp, C.c_int64]
         _lib.gso_sh_eval.argtypes = [C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _bp]
+        _lib.gso_activate.argtypes = [C.c_int] + [_fp] * 6
+        _lib.gso_activate_bwd.argtypes = [C.c_int] + [_fp] * 6
         _lib.gso_dist2.argtypes = [C.c_int, _fp, _fp]
         _lib.gso_dist2_strided.argtypes = [C.c_int, _fp, _fp, C.c_int]
         _lib.gso_ssim_fwd.argtypes = [C.c_int] * 4 + [C.c_float] * 2 + [_fp] * 6
@@ -259,6 +261,24 @@ def expf(x):
     y = np.empty_like(x)
     lib().gso_expf(_f(x), _f(y), x.size)
     return y
+
+
+def activate(opacity_logit, log_scaling, rotation_raw):
+    """(opacity, scales, rotations) as the kernels' raw-parameter mode computes them."""
+    lo, ls, rr = _c(opacity_logit).reshape(-1), _c(log_scaling), _c(rotation_raw)
+    P = ls.shape[0]
+    o, s, r = np.zeros(P, np.float32), np.zeros((P, 3), np.float32), np.zeros((P, 4), np.float32)
+    lib().gso_activate(P, _f(lo), _f(ls), _f(rr), _f(o), _f(s), _f(r))
+    return o, s, r
+
+
+def activate_bwd(opacity_logit, log_scaling, rotation_raw, g_opacity, g_scales, g_rotations):
+    """Chain rule through the activations: gradients w.r.t. the raw parameters."""
+    lo, ls, rr = _c(opacity_logit).reshape(-1), _c(log_scaling), _c(rotation_raw)
+    go, gs, gr = (np.array(a, np.float32, copy=True, order="C") for a in (g_opacity, g_scales, g_rotations))
+    go = go.reshape(-1)
+    lib().gso_activate_bwd(ls.shape[0], _f(lo), _f(ls), _f(rr), _f(go), _f(gs), _f(gr))
+    return go, gs, gr
 
 
 def sh_eval(deg, pos, campos, shs):
