@@ -2,21 +2,26 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one training iteration of the hot path on one view of a synthetic
-6M-Gaussian street scene at 1920x1080 (SH degree 3, 4 `reps` channels,
-antialiasing on): activations -> rasterizer forward -> L1 + fused-ssim loss ->
-rasterizer backward, exactly the calls train.py:188-253 makes into the three
-operator packages.  With N > 1 (one process per GPU, launched by
-torch.distributed.run) every rank renders its own camera of an N-view batch
-from a full replica and the parameter gradients are all-reduced with RCCL:
-weak scaling, value = views per second over the whole job.
+One iteration ("it") is what one iteration of the reference's train.py:188-253
+does with the three operator packages on one view of a synthetic 6M-Gaussian
+street scene at 1920x1080 (SH degree 3, 4 `reps` channels, antialiasing on):
+activations -> rasterizer forward -> L1 + fused-ssim loss -> rasterizer
+backward.  A step is a batch of V views per GPU (default 8, different cameras)
+whose parameter gradients accumulate, followed with N > 1 by one RCCL sum
+all-reduce of the 63 floats per Gaussian.  Every rank holds a full replica and
+renders its own cameras: weak scaling, value = views per second over the
+whole job.  The step goes through `GaussianRasterizer.forward_params` (raw
+parameters; activations, SH concatenation and gradient accumulation inside the
+kernels); with N = 1 the same iteration through the unchanged reference
+signature (torch activations + torch.cat in front of `forward`) is timed too
+and reported as `reference_api_it_s`.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      for the kernel that took the most time, from HIP events recorded
                 inside the timed region on the launching stream;
-  cpu_baseline  the CPU checker (oracle/) timed on this host's cores on a
-                bounded sample of the same workload (N = 1 only);
-  kernels       per-kernel mean milliseconds of the timed region;
+  kernels       per-kernel mean milliseconds and achieved algorithmic GB/s;
+  cpu_baseline  the CPU checker (oracle/) timed on this host's cores on one
+                view of the same workload (N = 1 only);
   render_fps / sort_GBps   the other two parts of the headline metric.
 """
 import argparse
@@ -48,9 +53,9 @@ def build_params(sc, dev):
         xyz=t(sc["means3D"]).requires_grad_(True),
         features_dc=t(sc["shs"][:, :1]).contiguous().requires_grad_(True),
         features_rest=t(sc["shs"][:, 1:]).contiguous().requires_grad_(True),
+        opacity=t(np.log(op / (1 - op))).requires_grad_(True),
         scaling=t(np.log(sc["scales"])).requires_grad_(True),
         rotation=t(sc["rotations"]).requires_grad_(True),
-        opacity=t(np.log(op / (1 - op))).requires_grad_(True),
         reps=t(sc["reps"]).requires_grad_(True),
     )
 
@@ -65,16 +70,24 @@ def make_settings(cam, dev, sh_degree):
         antialiasing=True)
 
 
-def render(params, rs):
-    """gaussian_renderer/__init__.py:49-169: activations + rasterizer call."""
+def render_reference_api(params, rs):
+    """gaussian_renderer/__init__.py:49-169: activations + rasterizer call, unchanged signature."""
     from diff_gaussian_rasterization import GaussianRasterizer
     means2D = torch.zeros_like(params["xyz"], requires_grad=True)
     shs = torch.cat((params["features_dc"], params["features_rest"]), dim=1)
-    out = GaussianRasterizer(rs)(
+    return GaussianRasterizer(rs)(
         means3D=params["xyz"], means2D=means2D, opacities=torch.sigmoid(params["opacity"]), shs=shs,
         scales=torch.exp(params["scaling"]), rotations=torch.nn.functional.normalize(params["rotation"]),
         reps=params["reps"])
-    return out
+
+
+def render_params(params, rs, sink=None):
+    """The same render from the raw parameters (activations and concatenation in the kernels)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    means2D = torch.zeros_like(params["xyz"], requires_grad=True)
+    return GaussianRasterizer(rs).forward_params(
+        params["xyz"], means2D, params["features_dc"], params["features_rest"], params["opacity"], params["scaling"],
+        params["rotation"], params["reps"], grad_sink=sink)
 
 
 def train_loss(out, gt, lambda_dssim=0.2, lambda_rep=0.01):
@@ -88,39 +101,38 @@ def train_loss(out, gt, lambda_dssim=0.2, lambda_rep=0.01):
 
 
 class KernelTimer:
-    """HIP events recorded by the library around its kernels, one set per step."""
+    """HIP events recorded by the library around its kernels, one set per rendered view."""
 
-    def __init__(self, steps):
+    PAIRS = {"preprocess": (0, 1), "scan": (1, 2), "depth_order": (3, 4), "emit_keys": (4, 5), "sort": (5, 6),
+             "tile_ranges": (6, 7), "render_fwd": (7, 8), "finish_stats": (8, 9), "bwd_clear": (10, 11),
+             "render_bwd": (11, 12), "preprocess_bwd": (12, 13)}
+
+    def __init__(self, sets):
         import _gsplat_lib as G
         self.G = G
         self.n = G.NUM_PROFILE_EVENTS
-        self.events = [[torch.cuda.Event(enable_timing=True) for _ in range(self.n)] for _ in range(steps)]
+        self.events = [[torch.cuda.Event(enable_timing=True) for _ in range(self.n)] for _ in range(sets)]
         for row in self.events:
             for e in row:
                 e.record()  # creates the underlying hipEvent_t
         torch.cuda.synchronize()
-        self.arrays = []
-        for row in self.events:
-            arr = (C.c_void_p * self.n)(*[e.cuda_event for e in row])
-            self.arrays.append(arr)
+        self.arrays = [(C.c_void_p * self.n)(*[e.cuda_event for e in row]) for row in self.events]
 
-    def arm(self, step):
-        self.G.set_profile_events(self.arrays[step] if step is not None else None)
+    def arm(self, i):
+        self.G.set_profile_events(self.arrays[i] if i is not None else None)
 
     def means_ms(self, fwd_only=False):
-        pairs = {"preprocess": (0, 1), "scan": (1, 2), "depth_order": (3, 4), "emit_keys": (4, 5), "sort": (5, 6),
-                 "tile_ranges": (6, 7), "render_fwd": (7, 8), "finish_stats": (8, 9)}
-        if not fwd_only:
-            pairs.update({"bwd_clear": (10, 11), "render_bwd": (11, 12), "preprocess_bwd": (12, 13)})
         out = {}
-        for k, (a, b) in pairs.items():
+        for k, (a, b) in self.PAIRS.items():
+            if fwd_only and a >= 10:
+                continue
             out[k] = float(np.mean([row[a].elapsed_time(row[b]) for row in self.events]))
         return out
 
 
 def algorithmic_bytes(kernel, P, visible, R, HW, passes):
-    """Bytes one launch must move at least, per the per-unit figures of the
-    hot-path scope table (reference data layout)."""
+    """Bytes one launch must move at least (reference data layout): per-unit
+    figures times the units one launch processes."""
     return {
         "preprocess": 315.0 * visible + 20.0 * (P - visible),
         "depth_order": P * (28.0 + 8.0 + 4 * 24.0),
@@ -133,16 +145,21 @@ def algorithmic_bytes(kernel, P, visible, R, HW, passes):
     }.get(kernel)
 
 
-def cpu_baseline(P_full, W, H, seed, stride=8):
-    """The CPU checker on every `stride`-th Gaussian of the same scene and camera."""
+# What bounds each kernel (the blend kernels stop early per pixel and are limited by
+# VALU / LDS issue, not by the bytes they move; the others stream through HBM).
+BOUND = {"preprocess": "hbm", "depth_order": "hbm", "emit_keys": "hbm", "sort": "hbm", "tile_ranges": "hbm",
+         "render_fwd": "valu+lds", "render_bwd": "valu+lds+atomics", "preprocess_bwd": "hbm"}
+
+
+def cpu_baseline(P_full, W, H, seed):
+    """The CPU checker on one whole view of the same scene (camera 0)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gs_oracle
     import synth
     sc = synth.street_scene(P_full, W, H, seed=seed)
-    sub = {k: (v[::stride].copy() if isinstance(v, np.ndarray) else v) for k, v in sc.items()}
     gt = np.random.default_rng(0).random((3, H, W)).astype(np.float32)
     t0 = time.time()
-    f = gs_oracle.forward_from_scene(sub, antialiasing=True)
+    f = gs_oracle.forward_from_scene(sc, antialiasing=True)
     img = np.clip(f.out_color, 0, 1)[None]
     m, d1, d2, d3 = gs_oracle.ssim_fwd(img, gt[None])
     dl = np.full(img.shape, -0.2 / img.size, np.float32)
@@ -150,9 +167,19 @@ def cpu_baseline(P_full, W, H, seed, stride=8):
     g_l1 = 0.8 * np.sign(img[0] - gt) / img[0].size
     f.backward((g_ssim + g_l1).astype(np.float32), None, np.full((4, H, W), 0.01 / (4 * H * W), np.float32))
     dt = time.time() - t0
-    return {"value": 1.0 / (dt * stride), "unit": "it/s", "cores": gs_oracle.num_threads(), "kind": "port",
-            "sample": f"every {stride}th Gaussian ({sub['means3D'].shape[0]} of {P_full}), same camera {W}x{H}, "
-                      f"fwd+ssim+bwd took {dt:.2f} s (R={f.R}); value = 1/({stride} x seconds), linear in R"}
+    return {"value": 1.0 / dt, "unit": "it/s", "cores": gs_oracle.num_threads(), "kind": "port",
+            "sample": f"one whole view (camera 0, {P_full} Gaussians, {W}x{H}, R={f.R}): forward + ssim + backward "
+                      f"of the OpenMP checker took {dt:.2f} s"}
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch from the rocprofv3 --pmc passes of this command, if a summary was committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return {}
 
 
 def main():
@@ -160,10 +187,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--views-per-gpu", type=int, default=8, help="views rendered per GPU per step (gradient accumulation)")
     ap.add_argument("--gaussians", type=int, default=6_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--api", choices=("params", "reference"), default="params",
+                    help="params: forward_params (raw parameters); reference: unchanged reference signature")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-view / reference-API / FPS measurements")
     ap.add_argument("--fwd-only", action="store_true", help="time rendering only (render FPS)")
     args = ap.parse_args()
 
@@ -180,30 +211,54 @@ def main():
 
     import synth
     import gsdp
-    P, W, H = args.gaussians, args.width, args.height
+    from diff_gaussian_rasterization import ParamGradSink
+    P, W, H, V = args.gaussians, args.width, args.height, max(1, args.views_per_gpu)
     seed = 2
     t0 = time.time()
-    sc = synth.street_scene(P, W, H, seed=seed, cam_index=rank, n_cams=max(world, 1))
+    sc = synth.street_scene(P, W, H, seed=seed)
     params = build_params(sc, dev)
-    rs = make_settings(sc["camera"], dev, sc["sh_degree"])
-    gt = torch.rand((3, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(1 + rank))
-    leaves = list(params.values())
+    sh_degree = sc["sh_degree"]
     del sc
+    n_cams = world * V
+    views = []
+    for v in range(V):
+        ci = rank * V + v
+        cam = synth.street_camera(W, H, ci, n_cams)
+        gt = torch.rand((3, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(1 + ci))
+        views.append((make_settings(cam, dev, sh_degree), gt))
+    leaves = list(params.values())
+    use_params = args.api == "params"
+    sink = ParamGradSink(*leaves) if use_params else None
     log(f"[rank {rank}] scene ready in {time.time() - t0:.1f}s")
 
-    def step(k=None, timer=None):
-        if timer is not None:
-            timer.arm(k)
+    def one_view(rs, gt):
         if args.fwd_only:
             with torch.no_grad():
-                return render(params, rs)
-        for p in leaves:
-            p.grad = None
-        out = render(params, rs)
-        loss = train_loss(out, gt)
-        loss.backward()
-        if world > 1:
+                return render_params(params, rs) if use_params else render_reference_api(params, rs)
+        out = render_params(params, rs, sink) if use_params else render_reference_api(params, rs)
+        train_loss(out, gt).backward()
+        return out
+
+    reducer_ms = []
+
+    def step(k=None, timer=None):
+        if use_params:
+            sink.begin_step()
+        else:
+            for p in leaves:
+                p.grad = None
+        out = None
+        for v, (rs, gt) in enumerate(views):
+            if timer is not None:
+                timer.arm(k * V + v)
+            out = one_view(rs, gt)
+        if world > 1 and not args.fwd_only:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             gsdp.GradReducer().start([p.grad for p in leaves]).wait()
+            e1.record()
+            if k is not None:
+                reducer_ms.append((e0, e1))
         return out
 
     def sync():
@@ -214,7 +269,7 @@ def main():
     for _ in range(args.warmup):
         out = step()
     sync()
-    timer = KernelTimer(args.steps)
+    timer = KernelTimer(args.steps * V)
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -228,62 +283,109 @@ def main():
         dt = float(tmax.item())
 
     kernels = timer.means_ms(args.fwd_only)
-    visible = int((out[1] > 0).sum().item())
-    # number of instances of the last step
-    import _gsplat_lib as G
-    R = None
-    try:
-        R = int(out[0].grad_fn.num_rendered) if out[0].grad_fn is not None else None
-    except Exception:
-        R = None
-    if R is None:
-        with torch.no_grad():
-            from diff_gaussian_rasterization import _C as RC
-            e = torch.Tensor([])
-            shs = torch.cat((params["features_dc"], params["features_rest"]), dim=1)
-            R = RC.rasterize_gaussians(rs.bg, params["xyz"], e, torch.sigmoid(params["opacity"]),
-                                       torch.exp(params["scaling"]), torch.nn.functional.normalize(params["rotation"]),
-                                       1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, shs,
-                                       rs.sh_degree, rs.campos, False, True, False, params["reps"])[0]
     gx, gy = (W + 15) // 16, (H + 15) // 16
     passes = ((gx * gy).bit_length() + 7) // 8   # the instance sort only orders the tile bits
 
-    # render FPS (forward only) and the sort rate, measured after the timed region
-    render_fps = None
-    if not args.fwd_only and rank == 0:
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        nfr = 10
-        with torch.no_grad():
-            for _ in range(nfr):
-                render(params, rs)
-        torch.cuda.synchronize()
-        render_fps = nfr / (time.perf_counter() - t1)
+    # workload counters of this rank's views (outside the timed region)
+    vis_l, R_l = [], []
+    with torch.no_grad():
+        for rs, _ in views:
+            o = render_params(params, rs)
+            vis_l.append(int((o[1] > 0).sum().item()))
+        from diff_gaussian_rasterization import _C as RC
+        e = torch.Tensor([])
+        for rs, _ in views:
+            R_l.append(int(RC.rasterize_gaussians(
+                rs.bg, params["xyz"], e, params["opacity"], params["scaling"], params["rotation"], 1.0, e,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, params["features_dc"], rs.sh_degree,
+                rs.campos, False, True, False, params["reps"], sh_rest=params["features_rest"], raw_params=True)[0]))
+    visible, R = float(np.mean(vis_l)), float(np.mean(R_l))
+
+    extras = {}
+    if rank == 0 and world == 1 and not args.fwd_only and not args.no_extras:
+        rs0, gt0 = views[0]
+
+        def timed(fn, n):
+            fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return n / (time.perf_counter() - t1)
+
+        def it_params():
+            sink.begin_step() if use_params else None
+            o = render_params(params, rs0, sink)
+            train_loss(o, gt0).backward()
+
+        def it_reference():
+            for p in leaves:
+                p.grad = None
+            train_loss(render_reference_api(params, rs0), gt0).backward()
+
+        def fps_params():
+            with torch.no_grad():
+                render_params(params, rs0)
+
+        def fps_reference():
+            with torch.no_grad():
+                render_reference_api(params, rs0)
+
+        if use_params:
+            extras["single_view_it_s"] = timed(it_params, 20)
+        saved = [p.grad for p in leaves]
+        extras["reference_api_it_s"] = timed(it_reference, 20)
+        for p, g in zip(leaves, saved):
+            p.grad = g
+        extras["render_fps"] = timed(fps_params, 20)
+        extras["render_fps_reference_api"] = timed(fps_reference, 20)
 
     if rank == 0:
+        traffic = load_pmc_traffic()
+        per_kernel = {}
+        for k, ms in kernels.items():
+            ab = algorithmic_bytes(k, P, visible, R, H * W, passes)
+            ent = {"ms": ms}
+            if ab:
+                ent.update({"algorithmic_GBps": ab / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                            "bound": BOUND.get(k)})
+                if k in traffic:
+                    ent["hbm_traffic_bytes"] = traffic[k]
+            per_kernel[k] = ent
         dom = max((k for k in kernels if algorithmic_bytes(k, P, visible, R, H * W, passes)), key=lambda k: kernels[k])
         ab = algorithmic_bytes(dom, P, visible, R, H * W, passes)
         achieved = ab / (kernels[dom] * 1e-3) / 1e9
+        views_total = world * V * args.steps
         res = {
-            "metric": "render FPS (forward only)" if args.fwd_only else "train it/s (hot path: fwd + L1/fused-ssim + bwd)",
-            "value": world * args.steps / dt,
+            "metric": "render FPS (forward only)" if args.fwd_only else
+                      "train it/s (1 it = 1 view: fwd + L1/fused-ssim loss + bwd, as one iteration of the reference)",
+            "value": views_total / dt,
             "unit": "frames/s" if args.fwd_only else "it/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"street scene, {P} Gaussians SH3 + 4 reps, {W}x{H}, antialiasing, "
-                                   f"1 view per GPU per step" + (", forward only" if args.fwd_only else
-                                                                   ", fwd + fused-ssim loss + bwd, no optimizer"),
-                       "gaussians": P, "visible": visible, "num_rendered": R, "image": [W, H],
-                       "parallelism": f"view-sharded x{world}" if world > 1 else "single GPU"},
+            "config": {"workload": f"street scene, {P} Gaussians SH3 + 4 reps, {W}x{H}, antialiasing; a step = {V} views "
+                                   f"per GPU (different cameras, gradients accumulate)" +
+                                   (", forward only" if args.fwd_only else ", each fwd + fused-ssim loss + bwd, then one "
+                                    "gradient all-reduce when n_gpus > 1; no optimizer"),
+                       "api": "forward_params (raw parameters)" if use_params else "reference signature",
+                       "gaussians": P, "views_per_gpu_per_step": V, "visible_mean": visible, "num_rendered_mean": R,
+                       "image": [W, H], "parallelism": f"view-sharded x{world}, full replicas" if world > 1 else "single GPU"},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "algorithmic_bytes_per_launch": ab, "ms_per_launch": kernels[dom]},
-            "kernels_ms": kernels,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic.get(dom),
+                         "algorithmic_bytes_per_launch": ab, "ms_per_launch": kernels[dom],
+                         "limited_by": BOUND.get(dom)},
+            "kernels": per_kernel,
             "sort_GBps": (R * 12.0 / (kernels["sort"] * 1e-3) / 1e9) if R else None,
-            "render_fps": render_fps,
         }
+        res.update(extras)
+        if world > 1 and reducer_ms:
+            ms = float(np.mean([a.elapsed_time(b) for a, b in reducer_ms]))
+            nbytes = float(sum(p.grad.numel() * 4 for p in leaves))
+            res["allreduce"] = {"ms": ms, "bytes": nbytes,
+                                "bus_GBps": 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(P, W, H, seed)

@@ -13,9 +13,10 @@
 //   SH_CAT16    one [P,16,3] tensor: each wave moves its 64 rows as 16-byte
 //               chunks in address order through a padded LDS image
 //               (sh_rows_load / sh_rows_store);
-//   SH_SPLIT16  [P,1,3] + [P,15,3] tensors: the 180-byte rows of the second
-//               go through a linear LDS image one dword per lane (row stride
-//               45 dwords is odd, so per-lane row access is conflict-free);
+//   SH_SPLIT16  [P,1,3] + [P,15,3] tensors: the wave's 64 x 180 bytes of the
+//               second are contiguous and move as 16-byte chunks through a
+//               linear LDS image (rest_rows_copy); a lane reads and writes its
+//               row dword by dword (row stride 45 dwords is odd: conflict-free);
 //   SH_DIRECT   any other size: each lane walks its own row in global memory.
 #include "kernels.h"
 
@@ -62,12 +63,6 @@ struct ShLds {
     static constexpr int bytes_per_wave =
         MODE == SH_CAT16 ? SH_WAVE_LDS_F4 * 16 : (MODE == SH_SPLIT16 ? REST_WAVE_F * 4 : 0);
 };
-
-template <bool ACC>
-__device__ __forceinline__ void put(float* p, float v) {
-    if (ACC) *p += v;
-    else *p = v;
-}
 
 // Everything for one rendered Gaussian.
 template <int MODE>
@@ -232,14 +227,16 @@ __device__ __forceinline__ void pre_bwd_unrendered(const PreBwdArgs& a, size_t i
     a.dL_dcolors[3 * i] = a.dL_dcolors[3 * i + 1] = a.dL_dcolors[3 * i + 2] = 0.f;
 #pragma unroll
     for (int k = 0; k < 6; ++k) a.dL_dcov3D[6 * i + k] = 0.f;
+    if (MODE == SH_SPLIT16) {  // also when accumulating: a 16-byte chunk can straddle a rendered neighbour's row
+#pragma unroll
+        for (int k = 0; k < REST_ROW_F; ++k) lds[lane * REST_ROW_F + k] = 0.0f;
+    }
     if (a.accumulate) return;  // adding zero: the parameter gradients stay as they are
     if (MODE == SH_CAT16) {
         float4* lds4 = reinterpret_cast<float4*>(lds);
 #pragma unroll
         for (int ch = 0; ch < SH_ROW_CHUNKS; ++ch) lds4[lane * SH_LDS_STRIDE + ch] = make_float4(0, 0, 0, 0);
     } else if (MODE == SH_SPLIT16) {
-#pragma unroll
-        for (int k = 0; k < REST_ROW_F; ++k) lds[lane * REST_ROW_F + k] = 0.0f;
         a.dL_dsh[3 * i] = a.dL_dsh[3 * i + 1] = a.dL_dsh[3 * i + 2] = 0.f;
     } else if (MODE == SH_DIRECT) {
         if (a.shs_rest) {
@@ -258,6 +255,42 @@ __device__ __forceinline__ void pre_bwd_unrendered(const PreBwdArgs& a, size_t i
         reinterpret_cast<float4*>(a.dL_drotations)[i] = make_float4(0, 0, 0, 0);
     }
     if (a.DIM == 4) reinterpret_cast<float4*>(a.dL_dreps)[i] = make_float4(0, 0, 0, 0);
+}
+
+// The wave's block of the [P,15,3] tensor (nrows x 45 dwords, contiguous, 16-byte
+// aligned because a wave starts at a multiple of 64 rows) between global memory
+// and its linear LDS image, 16 bytes per lane and step.  A chunk can straddle
+// two rows; it moves if either row's bit is set in `rows`.
+// OP 0: LDS = global, 1: global = LDS, 2: global += LDS.
+template <int OP>
+__device__ __forceinline__ void rest_rows_copy(float* __restrict__ g, float* lds, uint64_t rows, int nrows, int lane) {
+    const int total = nrows * REST_ROW_F;
+    float4* g4 = reinterpret_cast<float4*>(g);
+    float4* l4 = reinterpret_cast<float4*>(lds);
+#pragma unroll
+    for (int it = 0; it < (REST_WAVE_F / 4 + 63) / 64; ++it) {
+        const int i = it * 64 + lane;
+        if (4 * i + 3 < total) {
+            const int r0 = (4 * i) / REST_ROW_F, r1 = (4 * i + 3) / REST_ROW_F;
+            if (((rows >> r0) | (rows >> r1)) & 1ull) {
+                if (OP == 0) {
+                    l4[i] = g4[i];
+                } else if (OP == 1) {
+                    g4[i] = l4[i];
+                } else {
+                    const float4 o = g4[i], v = l4[i];
+                    g4[i] = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+                }
+            }
+        }
+    }
+    // up to three dwords left when the last wave is partial
+    const int f = (total & ~3) + lane;
+    if (lane < 3 && f < total && ((rows >> (f / REST_ROW_F)) & 1ull)) {
+        if (OP == 0) lds[f] = g[f];
+        else if (OP == 1) g[f] = lds[f];
+        else g[f] += lds[f];
+    }
 }
 
 #ifndef PRE_BWD_WAVES
@@ -281,15 +314,7 @@ __global__ void __launch_bounds__(256, PRE_BWD_WAVES) preprocess_bwd_kernel(cons
         if (rows) sh_rows_load(a.shs + (size_t)wave_g0 * SH_ROW_F, reinterpret_cast<float4*>(lds), rows, nrows, lane);
         wave_lds_sync();
     } else if (MODE == SH_SPLIT16) {
-        if (rows) {
-            const float* g = a.shs_rest + (size_t)wave_g0 * REST_ROW_F;
-#pragma unroll 5
-            for (int it = 0; it < REST_ROW_F; ++it) {
-                const int f = it * 64 + lane;
-                const int r = f / REST_ROW_F;
-                if (r < nrows && ((rows >> r) & 1ull)) lds[f] = g[f];
-            }
-        }
+        if (rows) rest_rows_copy<0>(const_cast<float*>(a.shs_rest) + (size_t)wave_g0 * REST_ROW_F, lds, rows, nrows, lane);
         wave_lds_sync();
     }
     if (rendered) pre_bwd_rendered<MODE>(a, (size_t)idx, lds, lane);
@@ -303,20 +328,9 @@ __global__ void __launch_bounds__(256, PRE_BWD_WAVES) preprocess_bwd_kernel(cons
         wave_lds_sync();
         float* g = a.dL_dsh_rest + (size_t)wave_g0 * REST_ROW_F;
         if (a.accumulate) {
-            if (rows) {
-#pragma unroll 5
-                for (int it = 0; it < REST_ROW_F; ++it) {
-                    const int f = it * 64 + lane;
-                    const int r = f / REST_ROW_F;
-                    if (r < nrows && ((rows >> r) & 1ull)) g[f] += lds[f];
-                }
-            }
+            if (rows) rest_rows_copy<2>(g, lds, rows, nrows, lane);
         } else {
-#pragma unroll 5
-            for (int it = 0; it < REST_ROW_F; ++it) {
-                const int f = it * 64 + lane;
-                if (f < nrows * REST_ROW_F) g[f] = lds[f];
-            }
+            rest_rows_copy<1>(g, lds, ~0ull, nrows, lane);
         }
     }
 }

@@ -114,6 +114,13 @@ def ball_scene(P=100_000, seed=1, sh_coeffs=16, dim=4, width=800, height=800):
                 camera=cam, sh_degree=int(round(math.sqrt(sh_coeffs))) - 1)
 
 
+def street_camera(width, height, cam_index=0, n_cams=1, fovx_deg=60.0):
+    """Camera `cam_index` of `n_cams` on a 30 degree arc around the scene centre (0, 0, 20), looking at it."""
+    ang = 0.0 if n_cams <= 1 else math.radians(-15.0 + 30.0 * cam_index / (n_cams - 1))
+    eye = (20.0 * math.sin(ang), -0.3, 20.0 - 20.0 * math.cos(ang))
+    return make_camera(width, height, math.radians(fovx_deg), eye, (0.0, 0.5, 20.0))
+
+
 def street_scene(P, width, height, seed=2, sh_coeffs=16, dim=4, fovx_deg=60.0, cam_index=0, n_cams=1):
     """Outdoor-capture-like: 70 % of the points in a slab in front of the
     camera, 30 % Gaussian clutter around it; log-normal anisotropic scales."""
@@ -130,10 +137,7 @@ def street_scene(P, width, height, seed=2, sh_coeffs=16, dim=4, fovx_deg=60.0, c
     base = 0.02 * np.exp(0.8 * rng.standard_normal((P, 1)))
     scales = (base * np.exp(0.35 * rng.standard_normal((P, 3)))).astype(np.float32)
     rot, opac, sh, reps = _common_attrs(rng, P, sh_coeffs, dim)
-    # cameras on a 30 degree arc around the scene centre (0, 0, 20), all looking at it
-    ang = 0.0 if n_cams <= 1 else math.radians(-15.0 + 30.0 * cam_index / (n_cams - 1))
-    eye = (20.0 * math.sin(ang), -0.3, 20.0 - 20.0 * math.cos(ang))
-    cam = make_camera(width, height, math.radians(fovx_deg), eye, (0.0, 0.5, 20.0))
+    cam = street_camera(width, height, cam_index, n_cams, fovx_deg)
     return dict(means3D=xyz, scales=scales, rotations=rot, opacities=opac.reshape(P, 1), shs=sh, reps=reps,
                 camera=cam, sh_degree=int(round(math.sqrt(sh_coeffs))) - 1)
 
