@@ -123,6 +123,20 @@ constexpr int SH_ROW_CHUNKS = 12;     // float4 per row
 constexpr int SH_LDS_STRIDE = 13;     // float4 per row in LDS
 constexpr int SH_WAVE_LDS_F4 = 64 * SH_LDS_STRIDE;
 
+// Sum over the four rows of 16 lanes: every lane gets v[l%16] + v[l%16+16] + v[l%16+32] + v[l%16+48].
+// v_permlane32_swap exchanges the upper half of its first operand with the lower
+// half of its second, v_permlane16_swap the odd rows of the first with the even
+// rows of the second; fed the same value twice, the two results hold the two
+// halves (rows) side by side, so one add folds them.
+__device__ __forceinline__ float rows_sum4(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto h = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float s = __uint_as_float(h[0]) + __uint_as_float(h[1]);
+    const uint32_t us = __float_as_uint(s);
+    const auto q = __builtin_amdgcn_permlane16_swap(us, us, false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
 // Orders one wave's LDS writes before its later LDS reads (other lanes' data).
 // The LDS unit serves a wave's instructions in order, so no hardware wait is
 // needed; the wavefront-scope fences keep the compiler from moving accesses

@@ -5,7 +5,9 @@
 // actually blended.  The reference issues up to 14 global float atomics per
 // (pixel, Gaussian) pair; here the 14 gradient components of an instance are
 // summed over the wave's 64 pixels by a transposing DPP butterfly (15 lane
-// exchanges), over the four waves by LDS atomics, and leave the workgroup once
+// exchanges) and two row swaps, over the four waves by LDS atomics (16 lanes,
+// 16 different words: an LDS atomic whose lanes share a word serialises), and
+// leave the workgroup once
 // per (tile, instance) as a 64-byte GradRec update: 16 lanes add to 16
 // consecutive floats, so one wave instruction carries four complete line-half
 // atomics instead of 64 scattered ones.
@@ -192,11 +194,13 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
             }
 
             // 16 gradient components x 64 pixels -> 16 sums: transpose-reduce inside each
-            // row of 16 lanes, then the four rows meet in one LDS atomic per lane.
+            // row of 16 lanes, fold the four rows with two lane swaps, then 16 lanes add
+            // to 16 different LDS words (the four waves of the tile meet there).
             const float comp[16] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_c0, g_c1, g_c2, g_id,
                                     DIM == 4 ? g_rep[0] : 0.f, DIM == 4 ? g_rep[1] : 0.f,
                                     DIM == 4 ? g_rep[2] : 0.f, DIM == 4 ? g_rep[3] : 0.f, 0.f, 0.f};
-            atomicAdd(&s_acc[j][lane & 15], row_transpose_sum16(comp, lane));
+            const float tot = rows_sum4(row_transpose_sum16(comp, lane));
+            if (lane < 16) atomicAdd(&s_acc[j][lane], tot);
         }
         __syncthreads();
         // 16 lanes per instance: one 64-byte GradRec update

@@ -1,0 +1,81 @@
+"""Condenses gpurun_out/pmc/ (written by tools/collect_pmc.sh) into
+profiles/<tag>_pmc_summary.csv, profiles/<tag>_kernel_stats.csv and
+profiles/pmc_traffic.json (HBM bytes per launch per kernel, FETCH_SIZE doubled
+as measured for wide coalesced reads on gfx950, WRITE_SIZE as is; both are
+reported in KiB by rocprofv3).
+
+usage: python tools/pmc_summary.py TAG
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "pmc")
+KERNEL_KEYS = {  # kernel symbol substring -> bench.py kernel name
+    "preprocess_fwd_kernel": "preprocess", "depth_keys_kernel": "depth_order:keys", "order_sums_kernel": "depth_order:sums",
+    "emit_keys_kernel": "emit_keys", "onesweep_kernel": "sort:onesweep", "sort_hist_kernel": "sort:hist",
+    "sort_scan_hist_kernel": "sort:scan", "tile_ranges_kernel": "tile_ranges", "render_fwd_kernel": "render_fwd",
+    "render_bwd_kernel": "render_bwd", "preprocess_bwd_kernel": "preprocess_bwd", "ssim_fwd": "ssim_fwd",
+    "ssim_bwd": "ssim_bwd", "scan_blocks_kernel": "scan", "finish_gstat_kernel": "finish_stats"}
+
+
+def short(name):
+    for k, v in KERNEL_KEYS.items():
+        if k in name:
+            return v
+    return None
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    acc = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> values per dispatch
+    for path in glob.glob(os.path.join(SRC, "*", "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                k = short(row["Kernel_Name"])
+                if k:
+                    acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    counters = sorted({c for k in acc for c in acc[k]})
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    out = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.csv")
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "dispatches"] + counters)
+        for k in sorted(acc):
+            n = max(len(v) for v in acc[k].values())
+            w.writerow([k, n] + [("%.6g" % (sum(acc[k][c]) / len(acc[k][c])) if acc[k].get(c) else "") for c in counters])
+    print("wrote", out)
+    # HBM traffic per launch, merged per bench kernel name (sub-kernels summed per logical step)
+    traffic = defaultdict(float)
+    launches_per_step = {"sort:onesweep": 2, "sort:hist": 1, "sort:scan": 1}  # instance sort; the depth sort is listed apart
+    for k in acc:
+        fs = acc[k].get("FETCH_SIZE")
+        ws = acc[k].get("WRITE_SIZE")
+        if not fs or not ws:
+            continue
+        per_launch = (2.0 * sum(fs) / len(fs) + sum(ws) / len(ws)) * 1024.0
+        traffic[k] = per_launch
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic_detail.json"), "w") as f:
+        json.dump({k: traffic[k] for k in sorted(traffic)}, f, indent=1)
+    simple = {k: v for k, v in traffic.items() if ":" not in k}
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
+        json.dump({k: simple[k] for k in sorted(simple)}, f, indent=1)
+    print("wrote profiles/pmc_traffic.json", simple)
+    # kernel stats of the trace pass
+    for path in glob.glob(os.path.join(SRC, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        dst = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")
+        with open(path) as f, open(dst, "w") as g:
+            g.write(f.read())
+        print("wrote", dst)
+    j = os.path.join(SRC, "bench_under_rocprof.json")
+    if os.path.exists(j):
+        with open(j) as f, open(os.path.join(ROOT, "profiles", f"{tag}_bench_under_rocprof.json"), "w") as g:
+            g.write(f.read())
+
+
+if __name__ == "__main__":
+    main()
