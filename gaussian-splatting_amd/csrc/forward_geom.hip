@@ -112,20 +112,49 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs
     if (threadIdx.x == 0) a.block_sums[blockIdx.x] = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
 }
 
-// Exclusive scan of the per-block sums (one workgroup walks the array), total
-// instance count into total[0], overflow flag into total[1].
-__global__ void __launch_bounds__(256) scan_blocks_kernel(uint32_t* block_sums, int nb, uint64_t* total) {
-    __shared__ uint32_t s_tmp[8];
+// Exclusive scan of the per-block sums, total instance count into total[0],
+// overflow flag into total[1].  One workgroup of 1024 threads, 16 consecutive
+// sums per thread and step, so 23 k sums (6 M Gaussians) take two steps; the
+// running values are 64-bit so that an overflowing total is detected, not wrapped.
+constexpr int SCAN_THREADS = 1024, SCAN_ITEMS = 16;
+__global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* block_sums, int nb, uint64_t* total) {
+    __shared__ uint64_t s_wave[SCAN_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     uint64_t carry = 0;
-    for (int base = 0; base < nb; base += 256) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < nb ? block_sums[i] : 0;
-        uint32_t sum;
-        const uint32_t ex = block_scan_excl_256(v, s_tmp, &sum);
-        if (i < nb) block_sums[i] = (uint32_t)(carry + ex);
-        carry += sum;
+    for (int base = 0; base < nb; base += SCAN_THREADS * SCAN_ITEMS) {
+        const int i0 = base + tid * SCAN_ITEMS;
+        uint32_t v[SCAN_ITEMS];
+        uint64_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            v[k] = i0 + k < nb ? block_sums[i0 + k] : 0u;
+            mine += v[k];
+        }
+        uint64_t incl = mine;  // inclusive scan over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint64_t t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wave[w] = incl;
+        __syncthreads();
+        uint64_t before = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_THREADS / 64; ++k) {
+            const uint64_t t = s_wave[k];
+            if (k < w) before += t;
+            all += t;
+        }
+        __syncthreads();
+        uint64_t run = carry + before + incl - mine;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            if (i0 + k < nb) block_sums[i0 + k] = (uint32_t)run;
+            run += v[k];
+        }
+        carry += all;
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         block_sums[nb] = (uint32_t)carry;
         total[0] = carry;
         total[1] = carry >= (1ull << 30) ? 1 : 0;
@@ -254,7 +283,7 @@ hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, cons
 }
 
 hipError_t launch_scan_blocks(uint32_t* block_sums, int nb, uint64_t* total, hipStream_t st) {
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, block_sums, nb, total);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, block_sums, nb, total);
     return hipGetLastError();
 }
 
@@ -271,7 +300,7 @@ hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, const uint32_t*
     const int grid_x = (s.W + TILE_X - 1) / TILE_X;
     hipLaunchKernelGGL(order_sums_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, s.P, order, g.bin, g.order_sums);
     // total[] was read by the host already; the scan rewrites the same value
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, g.order_sums, nb, g.total);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, g.order_sums, nb, g.total);
     hipLaunchKernelGGL(emit_keys_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, s.P, grid_x, order, g.bin, g.order_sums,
                        keys, vals);
     return hipGetLastError();

@@ -6,7 +6,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc
-rm -rf "$OUT"; mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"   # (delete the local gpurun_out/pmc too before collecting: results are merged into it)
 BENCH="bench.py --steps 2 --warmup 1 --views-per-gpu 2 --no-extras --no-cpu-baseline $*"
 run_pass() {
     name=$1; shift
@@ -20,5 +20,5 @@ run_pass sq2 SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 run_pass tcc TCC_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE &&
 echo "== kernel trace" &&
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline $* > "$OUT/trace.log" 2>&1 &&
-tail -1 "$OUT/trace.log" > "$OUT/bench_under_rocprof.json" &&
+grep '^{"metric"' "$OUT/trace.log" > "$OUT/bench_under_rocprof.json" &&
 find "$OUT" -name "*.csv" | head -30

@@ -33,7 +33,12 @@ def short(name):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     acc = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> values per dispatch
+    newest = {}   # one file per pass: the latest (earlier collections may have left theirs behind)
     for path in glob.glob(os.path.join(SRC, "*", "**", "*counter_collection.csv"), recursive=True):
+        key = os.path.relpath(path, SRC).split(os.sep)[0]
+        if key not in newest or os.path.getmtime(path) > os.path.getmtime(newest[key]):
+            newest[key] = path
+    for path in newest.values():
         with open(path) as f:
             for row in csv.DictReader(f):
                 k = short(row["Kernel_Name"])
@@ -66,7 +71,8 @@ def main():
         json.dump({k: simple[k] for k in sorted(simple)}, f, indent=1)
     print("wrote profiles/pmc_traffic.json", simple)
     # kernel stats of the trace pass
-    for path in glob.glob(os.path.join(SRC, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    stats = sorted(glob.glob(os.path.join(SRC, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    for path in stats[-1:]:
         dst = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")
         with open(path) as f, open(dst, "w") as g:
             g.write(f.read())
