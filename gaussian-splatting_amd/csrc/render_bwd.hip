@@ -78,11 +78,7 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
     bg_dot_dpixel += a.bg[1] * dpix1;
     bg_dot_dpixel += a.bg[2] * dpix2;
 
-    float accum_rec0 = 0.f, accum_rec1 = 0.f, accum_rec2 = 0.f, accum_invd = 0.f;
-    float last_c0 = 0.f, last_c1 = 0.f, last_c2 = 0.f, last_invd = 0.f, last_alpha = 0.f;
-    float accum_rep[DIM > 0 ? DIM : 1], last_rep[DIM > 0 ? DIM : 1];
-#pragma unroll
-    for (int i = 0; i < (DIM > 0 ? DIM : 1); ++i) accum_rep[i] = last_rep[i] = 0.f;
+    float accum_S = 0.f, last_S = 0.f, last_alpha = 0.f;
 
     const float ddelx_dx = 0.5f * a.W;
     const float ddely_dy = 0.5f * a.H;
@@ -142,43 +138,39 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
             for (int i = 0; i < (DIM > 0 ? DIM : 1); ++i) g_rep[i] = 0.f;
 
             if (valid) {
-                T = T / (1.f - alpha);
+                // 1 / (1 - alpha) by v_rcp_f32 (1 ulp): the gradients are sums of atomics anyway, and an
+                // IEEE divide is ten instructions of the ~120 in this body.
+                const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                T = T * inv_1ma;
                 const float dchannel_dcolor = alpha * T;
-                float dL_dalpha = 0.0f;
-                {
-                    accum_rec0 = last_alpha * last_c0 + (1.f - last_alpha) * accum_rec0;
-                    last_c0 = q1.z;
-                    dL_dalpha += (q1.z - accum_rec0) * dpix0;
-                    g_c0 = dchannel_dcolor * dpix0;
-                    accum_rec1 = last_alpha * last_c1 + (1.f - last_alpha) * accum_rec1;
-                    last_c1 = q1.w;
-                    dL_dalpha += (q1.w - accum_rec1) * dpix1;
-                    g_c1 = dchannel_dcolor * dpix1;
-                    accum_rec2 = last_alpha * last_c2 + (1.f - last_alpha) * accum_rec2;
-                    last_c2 = q2.x;
-                    dL_dalpha += (q2.x - accum_rec2) * dpix2;
-                    g_c2 = dchannel_dcolor * dpix2;
-                }
+                // The reference keeps, per channel, accum = last_alpha * last_c + (1 - last_alpha) * accum
+                // and adds (c - accum) * dL_dpixel over the channels (backward.cu:618-660).  Only the
+                // sum is used, and it obeys the same recurrence with S = sum_ch c * dL_dpixel in the
+                // place of c: two scalars of state per pixel instead of two per channel.
+                float S = q1.z * dpix0;
+                S = fmaf(q1.w, dpix1, S);
+                S = fmaf(q2.x, dpix2, S);
+                g_c0 = dchannel_dcolor * dpix0;
+                g_c1 = dchannel_dcolor * dpix1;
+                g_c2 = dchannel_dcolor * dpix2;
                 if (DIM == 4) {
-                    const float rv[4] = {q2.z, q2.w, q3.x, q3.y};
+                    S = fmaf(q2.z, drep[0], S);
+                    S = fmaf(q2.w, drep[1], S);
+                    S = fmaf(q3.x, drep[2], S);
+                    S = fmaf(q3.y, drep[3], S);
 #pragma unroll
-                    for (int ch = 0; ch < 4; ++ch) {
-                        accum_rep[ch] = last_alpha * last_rep[ch] + (1.f - last_alpha) * accum_rep[ch];
-                        last_rep[ch] = rv[ch];
-                        dL_dalpha += (rv[ch] - accum_rep[ch]) * drep[ch];
-                        g_rep[ch] = dchannel_dcolor * drep[ch];
-                    }
+                    for (int ch = 0; ch < 4; ++ch) g_rep[ch] = dchannel_dcolor * drep[ch];
                 }
                 if (INVD) {
-                    const float invd = q2.y;
-                    accum_invd = last_alpha * last_invd + (1.f - last_alpha) * accum_invd;
-                    last_invd = invd;
-                    dL_dalpha += (invd - accum_invd) * dinvd;
+                    S = fmaf(q2.y, dinvd, S);
                     g_id = dchannel_dcolor * dinvd;
                 }
+                accum_S = fmaf(last_alpha, last_S - accum_S, accum_S);
+                last_S = S;
+                float dL_dalpha = S - accum_S;
                 dL_dalpha *= T;
                 last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
 
                 g_op = G * dL_dalpha;
                 const float dL_dG = co.w * dL_dalpha;
