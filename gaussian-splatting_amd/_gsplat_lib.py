@@ -80,6 +80,8 @@ def lib():
                                          C.POINTER(C.c_int)]
     L.gsr_layout.restype = C.c_int
     L.gsr_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(GsrLayout)]
+    L.gsr_sorted_keys_u64.restype = C.c_int
+    L.gsr_sorted_keys_u64.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, _vp]
     L.gsk_dist2_temp_bytes.restype = C.c_size_t
     L.gsk_dist2_temp_bytes.argtypes = [C.c_int]
     L.gsk_dist2.restype = C.c_int
@@ -96,7 +98,7 @@ def lib():
 
 EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backward_work_bytes",
             "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_mark_visible", "gsr_sort_temp_bytes",
-            "gsr_sort_pairs_u64_u32", "gsr_layout", "gsk_dist2_temp_bytes", "gsk_dist2", "gss_ssim_forward",
+            "gsr_sort_pairs_u64_u32", "gsr_layout", "gsr_sorted_keys_u64", "gsk_dist2_temp_bytes", "gsk_dist2", "gss_ssim_forward",
             "gss_ssim_backward", "gsr_status_string")
 
 

@@ -40,9 +40,10 @@ int check_scene(const GsrScene* s) {
     return GSR_OK;
 }
 
-int sort_end_bit(const GsrScene& s) {
-    const int gx = (s.W + TILE_X - 1) / TILE_X, gy = (s.H + TILE_Y - 1) / TILE_Y;
-    return 32 + (int)higher_msb((uint32_t)(gx * gy));
+// Bits of a tile id (the reference sorts its 64-bit keys on 32 + this many bits, rasterizer_impl.cu:373).
+int tile_bits(int W, int H) {
+    const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
+    return (int)higher_msb((uint32_t)(gx * gy));
 }
 
 }  // namespace
@@ -113,8 +114,8 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
             mark(s, GSR_EV_DEPTH_ORDER, st);
             GSR_TRY(launch_emit_keys(*s, g, g.dvals[ord], b.keys[0], b.vals[0], st));
             mark(s, GSR_EV_EMIT, st);
-            // emission order is (depth, index): only the tile bits are left to sort
-            GSR_TRY(launch_radix_sort(b.keys, b.vals, R, 32, sort_end_bit(*s), b.sort_temp, st, &res));
+            // emission order is (depth, index): the stable sort only has to order the tile ids
+            GSR_TRY(launch_radix_sort_u32(b.keys, b.vals, R, 0, tile_bits(s->W, s->H), b.sort_temp, st, &res, false));
             mark(s, GSR_EV_SORT, st);
         }
         GSR_TRY(launch_tile_ranges(b.keys[res], R, im.ranges, ntiles, st));
@@ -129,7 +130,7 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
     }
     if (debug && R > 0) {
         const SortTemp t = sort_temp_view(bin_view(binning_buffer, (size_t)R).sort_temp, (size_t)R,
-                                          sort_passes_for(32, sort_end_bit(*s)));
+                                          sort_passes_for(0, tile_bits(s->W, s->H)));
         uint32_t err = 0;
         if (hipMemcpy(&err, t.err, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess) return GSR_ERR_HIP;
         if (err) return GSR_ERR_SORT;
@@ -161,7 +162,7 @@ int gsr_backward(const GsrScene* s, const int* radii, const void* geom_buffer, c
     mark(s, GSR_EV_BWD_CLEAR, st);
     if (R > 0) {
         const BinView b = bin_view((void*)binning_buffer, (size_t)R);
-        const int res = sort_passes_for(32, sort_end_bit(*s)) & 1;
+        const int res = sort_passes_for(0, tile_bits(s->W, s->H)) & 1;
         GSR_TRY(launch_render_bwd(*s, g, im, b.vals[res], *io, acc, st));
     }
     mark(s, GSR_EV_BWD_RENDER, st);
@@ -211,9 +212,19 @@ int gsr_layout(int P, int W, int H, int64_t R, GsrLayout* out) {
     out->keys1 = (char*)b.keys[1] - z;
     out->vals0 = (char*)b.vals[0] - z;
     out->vals1 = (char*)b.vals[1] - z;
-    const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
-    out->sorted_buffer = sort_passes_for(32, 32 + (int)higher_msb((uint32_t)(gx * gy))) & 1;
+    out->sorted_buffer = sort_passes_for(0, tile_bits(W, H)) & 1;
     return GSR_OK;
+}
+
+int gsr_sorted_keys_u64(int P, int W, int H, int64_t R, const void* geom_buffer, const void* binning_buffer,
+                        uint64_t* keys_out, void* stream) {
+    if (P < 0 || W <= 0 || H <= 0 || R < 0) return GSR_ERR_ARG;
+    if (R == 0) return GSR_OK;
+    if (!geom_buffer || !binning_buffer || !keys_out) return GSR_ERR_ARG;
+    const GeomBuf g = geom_buf(geom_buffer, (size_t)P);
+    const BinView b = bin_view((void*)binning_buffer, (size_t)R);
+    const int res = sort_passes_for(0, tile_bits(W, H)) & 1;
+    return hip_status(launch_keys64(g, b.keys[res], b.vals[res], R, keys_out, (hipStream_t)stream));
 }
 
 size_t gsk_dist2_temp_bytes(int P) { return knn_temp_bytes(P); }

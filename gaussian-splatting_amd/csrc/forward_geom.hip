@@ -164,20 +164,28 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* blo
 // Depth keys for ordering the Gaussians front to back: the f32 bits of the
 // view-space depth (positive floats order like their bit patterns), all ones
 // for Gaussians that produce no instance so that they sort to the end.
-__global__ void __launch_bounds__(256) depth_keys_kernel(int P, const uint4* bin, uint64_t* keys, uint32_t* vals) {
+__global__ void __launch_bounds__(256) depth_keys_kernel(int P, const uint4* bin, uint32_t* keys, uint32_t* vals) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     const uint4 b = bin[i];
-    keys[i] = b.w ? (uint64_t)b.z : 0xFFFFFFFFull;
+    keys[i] = b.w ? b.z : 0xFFFFFFFFu;
     vals[i] = (uint32_t)i;
 }
 
-// Tiles touched per block of 256 Gaussians taken in depth order.
-__global__ void __launch_bounds__(PRE_BLOCK) order_sums_kernel(int P, const uint32_t* order, const uint4* bin,
-                                                               uint32_t* sums) {
+// The tile rectangles in depth order: sbin[i] = {rect origin, rect size, Gaussian
+// index, tiles} of the i-th Gaussian front to back (the one random gather of the
+// emission), and the tiles touched per block of 256 of them.
+__global__ void __launch_bounds__(PRE_BLOCK) order_gather_kernel(int P, const uint32_t* order, const uint4* bin,
+                                                                 uint4* sbin, uint32_t* sums) {
     __shared__ uint32_t s_tmp[4];
     const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
-    const uint32_t t = i < P ? bin[order[i]].w : 0u;
+    uint32_t t = 0;
+    if (i < P) {
+        const uint32_t gid = order[i];
+        const uint4 b = bin[gid];
+        sbin[i] = make_uint4(b.x, b.y, gid, b.w);
+        t = b.w;
+    }
     const uint32_t ws = wave_sum_u32(t);
     if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = ws;
     __syncthreads();
@@ -186,23 +194,22 @@ __global__ void __launch_bounds__(PRE_BLOCK) order_sums_kernel(int P, const uint
 
 // duplicateWithKeys (rasterizer_impl.cu:70-110), restated for the hardware:
 //  * Gaussians are visited in depth order (ties in index order), so the emitted
-//    list is already sorted by (depth, index) and the 64-bit radix sort that
-//    follows only has to order the tile bits: 2 passes instead of 6, with the
-//    same final list as sorting the reference's emission order on all bits;
+//    list is already sorted by (depth, index).  The reference's 64-bit key is
+//    (tile << 32 | depth bits); with the depth part already in order the stable
+//    sort that follows only has to look at the tile, so the key that is written
+//    and sorted is the 32-bit tile id: 2 passes over 8-byte pairs instead of 6
+//    over 12-byte pairs, with the same final list;
 //  * the instances of a block of 256 Gaussians are numbered consecutively and
 //    dealt to the threads round-robin, so work and stores are uniform however
 //    large individual splats are.
-__global__ void __launch_bounds__(PRE_BLOCK) emit_keys_kernel(int P, int grid_x, const uint32_t* order,
-                                                              const uint4* bin, const uint32_t* block_offsets,
-                                                              uint64_t* keys, uint32_t* vals) {
+__global__ void __launch_bounds__(PRE_BLOCK) emit_keys_kernel(int P, int grid_x, const uint4* sbin,
+                                                              const uint32_t* block_offsets, uint32_t* keys,
+                                                              uint32_t* vals) {
     __shared__ uint32_t s_tmp[8];
     __shared__ uint32_t s_off[PRE_BLOCK];
     __shared__ uint4 s_bin[PRE_BLOCK];
-    __shared__ uint32_t s_gid[PRE_BLOCK];
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-    const uint32_t gid = idx < P ? order[idx] : 0u;
-    const uint4 b = idx < P ? bin[gid] : make_uint4(0, 0, 0, 0);
-    s_gid[threadIdx.x] = gid;
+    const uint4 b = idx < P ? sbin[idx] : make_uint4(0, 0, 0, 0);
     uint32_t total;
     const uint32_t ex = block_scan_excl_256(b.w, s_tmp, &total);
     s_off[threadIdx.x] = ex;
@@ -220,27 +227,35 @@ __global__ void __launch_bounds__(PRE_BLOCK) emit_keys_kernel(int P, int grid_x,
         const uint32_t w = gb.y & 0xffffu;
         const uint32_t ty = q / w;
         const uint32_t tx = q - ty * w;
-        const uint32_t tile = ((gb.x >> 16) + ty) * (uint32_t)grid_x + (gb.x & 0xffffu) + tx;
-        keys[base + s] = ((uint64_t)tile << 32) | gb.z;
-        vals[base + s] = s_gid[lo];
+        keys[base + s] = ((gb.x >> 16) + ty) * (uint32_t)grid_x + (gb.x & 0xffffu) + tx;
+        vals[base + s] = gb.z;
     }
 }
 
-// rasterizer_impl.cu:115-137
-__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint64_t* keys, int64_t R, uint2* ranges) {
+// rasterizer_impl.cu:115-137, on the sorted tile ids.
+__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* keys, int64_t R, uint2* ranges) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= R) return;
-    const uint32_t cur = (uint32_t)(keys[i] >> 32);
+    const uint32_t cur = keys[i];
     if (i == 0) {
         ranges[cur].x = 0;
     } else {
-        const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
+        const uint32_t prev = keys[i - 1];
         if (cur != prev) {
             ranges[prev].y = (uint32_t)i;
             ranges[cur].x = (uint32_t)i;
         }
     }
     if (i == R - 1) ranges[cur].y = (uint32_t)R;
+}
+
+// The reference's 64-bit sort keys, rebuilt from the sorted tile ids and the
+// depth of each instance's Gaussian (for inspection and tests).
+__global__ void __launch_bounds__(256) keys64_kernel(const uint32_t* tile_keys, const uint32_t* point_list,
+                                                     const uint4* bin, int64_t R, uint64_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R) return;
+    out[i] = ((uint64_t)tile_keys[i] << 32) | bin[point_list[i]].z;
 }
 
 __global__ void __launch_bounds__(256) finish_gstat_kernel(int P, const float2* gstat, float* gauss_sum,
@@ -289,27 +304,35 @@ hipError_t launch_scan_blocks(uint32_t* block_sums, int nb, uint64_t* total, hip
 
 hipError_t launch_depth_order(const GeomBuf& g, int P, hipStream_t st, int* order_buffer) {
     hipLaunchKernelGGL(depth_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, g.bin, g.dkeys[0], g.dvals[0]);
-    uint64_t* k[2] = {g.dkeys[0], g.dkeys[1]};
+    uint32_t* k[2] = {g.dkeys[0], g.dkeys[1]};
     uint32_t* v[2] = {g.dvals[0], g.dvals[1]};
-    return launch_radix_sort(k, v, P, 0, 32, g.dsort_temp, st, order_buffer);
+    return launch_radix_sort_u32(k, v, P, 0, 32, g.dsort_temp, st, order_buffer, false);
 }
 
-hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, const uint32_t* order, uint64_t* keys, uint32_t* vals,
+hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, const uint32_t* order, uint32_t* keys, uint32_t* vals,
                             hipStream_t st) {
     const int nb = (s.P + PRE_BLOCK - 1) / PRE_BLOCK;
     const int grid_x = (s.W + TILE_X - 1) / TILE_X;
-    hipLaunchKernelGGL(order_sums_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, s.P, order, g.bin, g.order_sums);
+    hipLaunchKernelGGL(order_gather_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, s.P, order, g.bin, g.sbin, g.order_sums);
     // total[] was read by the host already; the scan rewrites the same value
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, g.order_sums, nb, g.total);
-    hipLaunchKernelGGL(emit_keys_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, s.P, grid_x, order, g.bin, g.order_sums,
-                       keys, vals);
+    hipLaunchKernelGGL(emit_keys_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, s.P, grid_x, g.sbin, g.order_sums, keys,
+                       vals);
     return hipGetLastError();
 }
 
-hipError_t launch_tile_ranges(const uint64_t* keys, int64_t R, uint2* ranges, int ntiles, hipStream_t st) {
+hipError_t launch_tile_ranges(const uint32_t* keys, int64_t R, uint2* ranges, int ntiles, hipStream_t st) {
     hipError_t e = hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), st);
     if (e != hipSuccess || R <= 0) return e;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, keys, R, ranges);
+    return hipGetLastError();
+}
+
+hipError_t launch_keys64(const GeomBuf& g, const uint32_t* tile_keys, const uint32_t* point_list, int64_t R,
+                         uint64_t* out, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(keys64_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, tile_keys, point_list, g.bin,
+                       R, out);
     return hipGetLastError();
 }
 

@@ -218,32 +218,6 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 constexpr int PRE_BLOCK = 256;  // Gaussians per preprocess / key-emit workgroup
 
-struct GeomView {
-    SplatRec* rec;          // [P]
-    float* cov3D;           // [P,6]
-    uint32_t* tiles;        // [P]
-    uint8_t* clamped;       // [P] bit c set: channel c was clamped at zero
-    uint32_t* block_sums;   // [nblocks] tiles per 256-Gaussian block, then exclusive offsets
-    uint64_t* total;        // [2] number of instances; [1] = overflow flag
-    size_t bytes;
-};
-
-inline GeomView geom_view(void* base, size_t P) {
-    GeomView v;
-    char* p = (char*)base;
-    const size_t nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
-    size_t off = 0;
-    auto take = [&](size_t n) { char* q = p ? p + off : nullptr; off = align_up(off + n, 256); return q; };
-    v.rec = (SplatRec*)take(P * sizeof(SplatRec));
-    v.cov3D = (float*)take(P * 6 * sizeof(float));
-    v.tiles = (uint32_t*)take(P * sizeof(uint32_t));
-    v.clamped = (uint8_t*)take(P);
-    v.block_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));
-    v.total = (uint64_t*)take(2 * sizeof(uint64_t));
-    v.bytes = off;
-    return v;
-}
-
 struct ImageView {
     float* final_T;       // [H*W]
     uint32_t* n_contrib;  // [H*W]
@@ -296,8 +270,8 @@ inline SortTemp sort_temp_view(void* base, size_t n, int passes) {
 }
 
 struct BinView {
-    uint64_t* keys[2];
-    uint32_t* vals[2];
+    uint32_t* keys[2];  // tile id of each instance, ping-pong
+    uint32_t* vals[2];  // Gaussian index of each instance, ping-pong
     void* sort_temp;
     size_t bytes;
 };
@@ -308,8 +282,8 @@ inline BinView bin_view(void* base, size_t R) {
     size_t off = 0;
     auto take = [&](size_t n) { char* q = p ? p + off : nullptr; off = align_up(off + n, 256); return q; };
     const size_t n = R ? R : 1;
-    v.keys[0] = (uint64_t*)take(n * sizeof(uint64_t));
-    v.keys[1] = (uint64_t*)take(n * sizeof(uint64_t));
+    v.keys[0] = (uint32_t*)take(n * sizeof(uint32_t));
+    v.keys[1] = (uint32_t*)take(n * sizeof(uint32_t));
     v.vals[0] = (uint32_t*)take(n * sizeof(uint32_t));
     v.vals[1] = (uint32_t*)take(n * sizeof(uint32_t));
     v.sort_temp = take(sort_temp_view(nullptr, n, SORT_MAX_PASSES).bytes);

@@ -18,8 +18,9 @@ struct GeomBuf {
     uint8_t* clamped;     // [P]
     uint32_t* block_sums; // [nblocks+1] tiles per block of 256 Gaussians in index order (gives the total)
     uint64_t* total;      // [2]
-    uint64_t* dkeys[2];   // [P] depth bits (all ones for Gaussians that are not rendered), ping-pong
+    uint32_t* dkeys[2];   // [P] depth bits (all ones for Gaussians that are not rendered), ping-pong
     uint32_t* dvals[2];   // [P] Gaussian index, ping-pong; the sorted one is the front-to-back order
+    uint4* sbin;          // [P] {x0 | y0<<16, w | h<<16, Gaussian index, tiles} in front-to-back order
     uint32_t* order_sums; // [nblocks+1] tiles per block of 256 Gaussians in depth order, then offsets
     void* dsort_temp;
     size_t bytes;
@@ -38,10 +39,11 @@ inline GeomBuf geom_buf(const void* base, size_t P) {
     v.clamped = (uint8_t*)take(P);
     v.block_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));
     v.total = (uint64_t*)take(2 * sizeof(uint64_t));
-    v.dkeys[0] = (uint64_t*)take(P * sizeof(uint64_t));
-    v.dkeys[1] = (uint64_t*)take(P * sizeof(uint64_t));
+    v.dkeys[0] = (uint32_t*)take(P * sizeof(uint32_t));
+    v.dkeys[1] = (uint32_t*)take(P * sizeof(uint32_t));
     v.dvals[0] = (uint32_t*)take(P * sizeof(uint32_t));
     v.dvals[1] = (uint32_t*)take(P * sizeof(uint32_t));
+    v.sbin = (uint4*)take(P * sizeof(uint4));
     v.order_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));
     v.dsort_temp = take(sort_temp_view(nullptr, P ? P : 1, 4).bytes);
     v.bytes = off;
@@ -64,16 +66,22 @@ hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, cons
 hipError_t launch_scan_blocks(uint32_t* block_sums, int nb, uint64_t* total, hipStream_t st);
 // Depth keys of all Gaussians, sorted front to back (stable): g.dvals[*order_buffer] is the order.
 hipError_t launch_depth_order(const GeomBuf& g, int P, hipStream_t st, int* order_buffer);
-// Key emission in depth order: only the tile bits of the keys remain to be sorted afterwards.
-hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, const uint32_t* order, uint64_t* keys, uint32_t* vals,
+// Key emission in depth order: (tile id, Gaussian index) pairs; only the tile remains to be sorted on.
+hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, const uint32_t* order, uint32_t* keys, uint32_t* vals,
                             hipStream_t st);
-hipError_t launch_tile_ranges(const uint64_t* keys, int64_t R, uint2* ranges, int ntiles, hipStream_t st);
+hipError_t launch_tile_ranges(const uint32_t* keys, int64_t R, uint2* ranges, int ntiles, hipStream_t st);
+// (tile << 32 | depth bits) of every sorted instance, as the reference's sort keys.
+hipError_t launch_keys64(const GeomBuf& g, const uint32_t* tile_keys, const uint32_t* point_list, int64_t R,
+                         uint64_t* out, hipStream_t st);
 hipError_t launch_finish_gstat(const GeomBuf& g, int P, float* gauss_sum, int* gauss_count, hipStream_t st);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);
 
 // Returns the index (0/1) of the buffer pair that holds the sorted result.
 hipError_t launch_radix_sort(uint64_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit, void* temp,
                              hipStream_t st, int* result_buffer);
+// The same with 32-bit keys.  hist_ready: the digit histograms in the temp area were filled by the caller.
+hipError_t launch_radix_sort_u32(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit,
+                                 void* temp, hipStream_t st, int* result_buffer, bool hist_ready);
 
 hipError_t launch_render_fwd(const GsrScene& s, const GsrForwardOut& o, const GeomBuf& g, const ImageView& im,
                              const uint32_t* point_list, hipStream_t st);

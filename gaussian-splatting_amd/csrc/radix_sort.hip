@@ -1,13 +1,14 @@
-// Stable LSD radix sort of (u64 key, u32 value) pairs, 8 bits per pass, one
-// sweep over the data per pass ("onesweep"): digit histograms of all passes
-// are taken in one upfront read; each pass then ranks an 8192-key tile in LDS,
-// obtains its global digit offsets by decoupled look-back over the preceding
-// tiles' published counts, and writes the tile out through an LDS staging
-// buffer so that stores to one digit's bucket are contiguous.
+// Stable LSD radix sort of (key, u32 value) pairs with u64 or u32 keys, 8 bits
+// per pass, one sweep over the data per pass ("onesweep"): digit histograms of
+// all passes are taken in one upfront read (or handed in by the producer of the
+// keys); each pass then ranks a 4096-key tile in LDS, obtains its global digit
+// offsets by decoupled look-back over the preceding tiles' published counts,
+// and writes the tile out through an LDS staging buffer so that stores to one
+// digit's bucket are contiguous.
 // Replaces cub::DeviceRadixSort::SortPairs at rasterizer_impl.cu:373-380.
 //
-// Traffic per pass: 12 B read + 12 B written per pair, plus 3 KiB of status
-// words per 8192-pair tile.
+// Traffic per pass: key + 4 B read and written per pair, plus 1 KiB of status
+// words per 4096-pair tile.
 #include "kernels.h"
 
 namespace gs {
@@ -26,14 +27,15 @@ constexpr int LOOK_BATCH = GS_LOOK_BATCH;
 
 int sort_passes_for(int begin_bit, int end_bit) { return (end_bit - begin_bit + 7) / 8; }
 
-__global__ void __launch_bounds__(256) sort_hist_kernel(const uint64_t* keys, int64_t n, int passes, int begin_bit,
+template <class K>
+__global__ void __launch_bounds__(256) sort_hist_kernel(const K* keys, int64_t n, int passes, int begin_bit,
                                                         int end_bit, uint32_t* ghist) {
     __shared__ uint32_t h[SORT_MAX_PASSES * 256];
     for (int i = threadIdx.x; i < passes * 256; i += 256) h[i] = 0;
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const uint64_t k = keys[i];
+        const K k = keys[i];
         for (int p = 0; p < passes; ++p) {
             const int bits = min(8, end_bit - begin_bit - 8 * p);
             const uint32_t d = (uint32_t)(k >> (begin_bit + 8 * p)) & ((1u << bits) - 1);
@@ -75,23 +77,25 @@ __device__ __forceinline__ uint32_t block_scan_excl_256_nw(uint32_t v, uint32_t*
     return base + incl - v;
 }
 
-// One pass over one tile of SORT_TILE = THREADS * ITEMS pairs.  LDS: the key
-// staging area (reused for the values once the keys have left), per-wave digit
-// counters and three 256-entry tables; about 75 KiB, two workgroups per CU.
+// One pass over one tile of SORT_TILE = THREADS * ITEMS pairs.  LDS: an
+// 8-byte-per-pair staging area (u64 keys first and then, once they have left,
+// the values; u32 keys and values side by side in one phase), per-wave digit
+// counters and three 256-entry tables; about 37 KiB.
 #ifndef GS_OS_BLOCKS
 #define GS_OS_BLOCKS 2
 #endif
-template <int THREADS, int ITEMS>
+template <class K, int THREADS, int ITEMS>
 __global__ void __launch_bounds__(THREADS, (GS_OS_BLOCKS * THREADS) / 256)
-onesweep_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint64_t* __restrict__ kout,
+onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __restrict__ kout,
                 uint32_t* __restrict__ vout, int64_t n, int shift, int bits, const uint32_t* __restrict__ gbase,
                 uint32_t* status, uint32_t* ticket, uint32_t* err) {
     constexpr int NW = THREADS / 64;
     constexpr int TILE = THREADS * ITEMS;
+    constexpr bool ONE_PHASE = sizeof(K) == 4;  // keys and values fit the staging area together
     static_assert(TILE == SORT_TILE, "tile size must match the status array layout");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* s_keys = reinterpret_cast<uint64_t*>(smem);                 // [TILE]
-    uint32_t* s_vals = reinterpret_cast<uint32_t*>(smem);                 // [TILE], second phase
+    K* s_keys = reinterpret_cast<K*>(smem);                               // [TILE]
+    uint32_t* s_vals = reinterpret_cast<uint32_t*>(smem) + (ONE_PHASE ? TILE : 0);  // [TILE]; u64 keys: second phase
     uint32_t* s_whist = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * 8);  // [NW][256]
     uint32_t* s_hist = s_whist + NW * 256;                                // [256]
     uint32_t* s_dstart = s_hist + 256;                                    // [256]
@@ -108,14 +112,14 @@ onesweep_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ v
     const int64_t wave_base = tile_base + (int64_t)w * (64 * ITEMS);
     const uint32_t dmask = (1u << bits) - 1;
 
-    uint64_t key[ITEMS];
+    K key[ITEMS];
     uint32_t val[ITEMS];
     uint32_t rank[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
         const int64_t i = wave_base + k * 64 + lane;
         const bool ok = i < n;
-        key[k] = ok ? kin[i] : ~0ull;
+        key[k] = ok ? kin[i] : (K)~(K)0;
         val[k] = ok ? vin[i] : 0u;
     }
 
@@ -213,14 +217,16 @@ onesweep_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ v
     }
     __syncthreads();
 
-    // 4. Keys: place in LDS in sorted order, stream out; remember each output
-    //    slot so that the values can follow through the same LDS.
+    // 4. Place the pairs in LDS in sorted order and stream them out.
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
         const bool ok = (wave_base + k * 64 + lane) < n;
         const uint32_t d = (uint32_t)(key[k] >> shift) & dmask;
         rank[k] = s_dstart[d] + s_whist[w * 256 + d] + rank[k];  // slot inside the tile
-        if (ok) s_keys[rank[k]] = key[k];
+        if (ok) {
+            s_keys[rank[k]] = key[k];
+            if (ONE_PHASE) s_vals[rank[k]] = val[k];
+        }
     }
     __syncthreads();
     const int64_t left = n - tile_base;
@@ -231,14 +237,17 @@ onesweep_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ v
         const uint32_t pos = tid + k * THREADS;
         dst[k] = 0;
         if (pos < tile_n) {
-            const uint64_t kk = s_keys[pos];
+            const K kk = s_keys[pos];
             const uint32_t d = (uint32_t)(kk >> shift) & dmask;
             dst[k] = s_gofs[d] + pos;
             kout[dst[k]] = kk;
+            if (ONE_PHASE) vout[dst[k]] = s_vals[pos];
         }
     }
+    if (ONE_PHASE) return;
     __syncthreads();
-    // 5. Values through the same staging area.
+    // 5. u64 keys: the values follow through the same staging area (the output
+    //    slots were kept in registers).
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
         if ((wave_base + k * 64 + lane) < n) s_vals[rank[k]] = val[k];
@@ -258,20 +267,29 @@ constexpr int OS_THREADS = GS_OS_THREADS;
 constexpr int OS_ITEMS = SORT_TILE / OS_THREADS;
 constexpr size_t OS_LDS = (size_t)SORT_TILE * 8 + (OS_THREADS / 64 + 4) * 256 * 4 + 64;
 
-hipError_t launch_radix_sort(uint64_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit, void* temp,
-                             hipStream_t st, int* result_buffer) {
+uint32_t* sort_prepare(void* temp, int64_t n, int passes, hipStream_t st, hipError_t* e) {
+    const SortTemp t = sort_temp_view(temp, (size_t)(n > 0 ? n : 1), passes);
+    *e = hipMemsetAsync(t.ghist, 0, t.zero_bytes, st);
+    return t.ghist;
+}
+
+template <class K>
+hipError_t radix_sort_impl(K* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit, void* temp,
+                           hipStream_t st, int* result_buffer, bool hist_ready) {
     *result_buffer = 0;
     if (n <= 0 || end_bit <= begin_bit) return hipSuccess;
     const int passes = sort_passes_for(begin_bit, end_bit);
     const SortTemp t = sort_temp_view(temp, (size_t)n, passes);
-    hipError_t e = hipMemsetAsync(t.ghist, 0, t.zero_bytes, st);
-    if (e != hipSuccess) return e;
     const int64_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
-    const int hist_blocks = (int)(tiles < 2048 ? tiles : 2048);
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(hist_blocks), dim3(256), 0, st, keys[0], n, passes, begin_bit, end_bit,
-                       t.ghist);
+    if (!hist_ready) {
+        hipError_t e = hipMemsetAsync(t.ghist, 0, t.zero_bytes, st);
+        if (e != hipSuccess) return e;
+        const int hist_blocks = (int)(tiles < 2048 ? tiles : 2048);
+        hipLaunchKernelGGL(sort_hist_kernel<K>, dim3(hist_blocks), dim3(256), 0, st, keys[0], n, passes, begin_bit,
+                           end_bit, t.ghist);
+    }
     hipLaunchKernelGGL(sort_scan_hist_kernel, dim3(passes), dim3(256), 0, st, t.ghist);
-    auto kern = onesweep_kernel<OS_THREADS, OS_ITEMS>;
+    auto kern = onesweep_kernel<K, OS_THREADS, OS_ITEMS>;
     hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)OS_LDS);
     if (ea != hipSuccess) return ea;
@@ -286,6 +304,16 @@ hipError_t launch_radix_sort(uint64_t* keys[2], uint32_t* vals[2], int64_t n, in
     }
     *result_buffer = cur;
     return hipGetLastError();
+}
+
+hipError_t launch_radix_sort(uint64_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit, void* temp,
+                             hipStream_t st, int* result_buffer) {
+    return radix_sort_impl<uint64_t>(keys, vals, n, begin_bit, end_bit, temp, st, result_buffer, false);
+}
+
+hipError_t launch_radix_sort_u32(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit,
+                                 void* temp, hipStream_t st, int* result_buffer, bool hist_ready) {
+    return radix_sort_impl<uint32_t>(keys, vals, n, begin_bit, end_bit, temp, st, result_buffer, hist_ready);
 }
 
 }  // namespace gs

@@ -179,10 +179,17 @@ int gsr_sort_pairs_u64_u32(uint64_t* keys0, uint32_t* vals0, uint64_t* keys1, ui
 typedef struct {
     size_t rec, cov3D, tiles, clamped, block_sums, total;           /* geometry buffer */
     size_t final_T, n_contrib, ranges;                               /* image buffer */
-    size_t keys0, keys1, vals0, vals1;                               /* binning buffer */
+    size_t keys0, keys1, vals0, vals1;                               /* binning buffer: u32 tile ids, u32 indices */
     int sorted_buffer;                                               /* which keys/vals pair is sorted */
 } GsrLayout;
 int gsr_layout(int P, int W, int H, int64_t num_rendered, GsrLayout* out);
+
+/* The sorted instance list as the reference holds it: point_list_keys[i] = (tile << 32 | depth bits)
+ * (rasterizer_impl.cu:93-104, BinningState::point_list_keys).  This implementation sorts
+ * (tile id, Gaussian index) pairs emitted in depth order and does not store the 64-bit keys; this
+ * call rebuilds them on the device from the buffers a forward pass left (keys_out: device, R x u64). */
+int gsr_sorted_keys_u64(int P, int W, int H, int64_t num_rendered, const void* geom_buffer,
+                        const void* binning_buffer, uint64_t* keys_out, void* stream);
 
 /* simple-knn: mean squared distance to the 3 nearest neighbours. */
 size_t gsk_dist2_temp_bytes(int P);

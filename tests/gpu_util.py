@@ -55,8 +55,16 @@ def read_internals(out, P, W, H):
     if R > 0:
         k = (lay.keys0, lay.keys1)[lay.sorted_buffer]
         v = (lay.vals0, lay.vals1)[lay.sorted_buffer]
-        res["keys"] = binning[k:k + R * 8].view(np.uint64)
+        res["tile_keys"] = binning[k:k + R * 4].view(np.uint32)
         res["point_list"] = binning[v:v + R * 4].view(np.uint32)
+        # the reference's 64-bit keys (tile << 32 | depth bits), rebuilt by the library
+        import torch
+        keys = torch.empty(R, dtype=torch.int64, device=out["geom"].device)
+        assert lib().gsr_sorted_keys_u64(P, W, H, R, out["geom"].data_ptr(), out["binning"].data_ptr(),
+                                         keys.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        torch.cuda.synchronize()
+        res["keys"] = keys.cpu().numpy().view(np.uint64)
+        assert np.array_equal((res["keys"] >> np.uint64(32)).astype(np.uint32), res["tile_keys"])
     else:
         res["keys"] = np.zeros(0, np.uint64)
         res["point_list"] = np.zeros(0, np.uint32)

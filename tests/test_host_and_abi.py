@@ -35,7 +35,7 @@ def test_size_queries_and_layout():
     assert L.gsr_geom_bytes(0) < L.gsr_geom_bytes(1000) < L.gsr_geom_bytes(100000)
     assert L.gsr_geom_bytes(6_000_000) >= 6_000_000 * (64 + 24 + 16 + 8 + 1)
     assert L.gsr_image_bytes(1920, 1080) >= 1920 * 1080 * 8 + 8160 * 8
-    assert L.gsr_binning_bytes(10_000_000) >= 10_000_000 * 24
+    assert L.gsr_binning_bytes(10_000_000) >= 10_000_000 * 16   # two (tile id, index) buffers of u32 pairs
     assert L.gsr_backward_work_bytes(1000) >= 64 * 1000
     assert L.gsr_sort_temp_bytes(1 << 20) > 0
     lay = GsrLayout()
