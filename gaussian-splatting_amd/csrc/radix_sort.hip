@@ -174,11 +174,7 @@ onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* 
     // 3. Decoupled look-back for digit `tid`, LOOK_BATCH predecessors per round trip.
     if (dthread) {
         uint32_t excl = 0;
-#ifdef GS_SORT_NOLOOK
-        if (false) {
-#else
         if (tile > 0) {
-#endif
             int64_t look = (int64_t)tile - 1;
             uint32_t spins = 0;
             bool done = false;
