@@ -344,6 +344,18 @@ def main():
         extras["render_fps"] = timed(fps_params, 20)
         extras["render_fps_reference_api"] = timed(fps_reference, 20)
 
+        # optimizer step over the same 6 M x 63 floats (not part of `value`): fused Adam kernel, dense and on
+        # the visible rows only, next to torch.optim.Adam as the reference configures it (gaussian_model.py:113)
+        from gsplat_optim import FusedGaussianAdam
+        groups = lambda: [{"params": [p], "lr": 1e-4} for p in leaves]
+        vis0 = render_params(params, rs0)[1] > 0
+        for name, opt, fn in (("fused_dense", FusedGaussianAdam(groups(), lr=0.0, eps=1e-15), lambda o: o.step()),
+                              ("fused_sparse", FusedGaussianAdam(groups(), lr=0.0, eps=1e-15),
+                               lambda o: o.step(vis0, vis0.numel())),
+                              ("torch_adam", torch.optim.Adam(groups(), lr=0.0, eps=1e-15), lambda o: o.step())):
+            extras.setdefault("optimizer_step_ms", {})[name] = 1e3 / timed(lambda: fn(opt), 10)
+            del opt
+
     if rank == 0:
         traffic = load_pmc_traffic()
         per_kernel = {}

@@ -260,6 +260,19 @@ int gss_ssim_backward(int B, int CH, int H, int W, float C1, float C2, const flo
                                       (hipStream_t)stream));
 }
 
+int gso_adam_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible,
+                    int64_t N, int M, double lr, double beta1, double beta2, double eps, double bias_correction1,
+                    double bias_correction2_sqrt, void* stream) {
+    if (N < 0 || M <= 0) return GSR_ERR_ARG;
+    if (N == 0) return GSR_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return GSR_ERR_ARG;
+    if (!(bias_correction1 > 0.0) || !(bias_correction2_sqrt > 0.0)) return GSR_ERR_ARG;
+    if (N * (int64_t)M >= (1ll << 40)) return GSR_ERR_OVERFLOW;
+    return hip_status(launch_adam(param, grad, exp_avg, exp_avg_sq, visible, N, M,
+                                  adam_const(lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt),
+                                  (hipStream_t)stream));
+}
+
 const char* gsr_status_string(int status) {
     switch (status) {
         case GSR_OK: return "ok";

@@ -366,6 +366,31 @@ GS_HD V4 act_normalize4_bwd(V4 y, float denom, V4 g) {
     return r;
 }
 
+// ---------------------------------------------------------------- optimizer
+// One Adam update of one element, in the operation order of torch.optim.Adam's
+// single-tensor path (exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2)
+// .addcmul_(grad, grad, value = 1 - beta2); denom = sqrt(exp_avg_sq) /
+// sqrt(bias_correction2) + eps; param.addcdiv_(exp_avg, denom, value = -lr /
+// bias_correction1)).  The constants are formed in double on the host, as
+// Python does there, and rounded once.  With step_size = lr and bc2_sqrt = 1
+// it is the update of the sparse Gaussian Adam (no bias correction).
+struct AdamConst {
+    float one_minus_beta1, beta2, one_minus_beta2, eps, step_size, bc2_sqrt;
+};
+inline AdamConst adam_const(double lr, double beta1, double beta2, double eps, double bc1, double bc2_sqrt) {
+    AdamConst c = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)(lr / bc1),
+                   (float)bc2_sqrt};
+    return c;
+}
+GS_HD float adam_update(float p, float g, float* m, float* v, const AdamConst& c) {
+    const float m1 = *m + c.one_minus_beta1 * (g - *m);
+    const float v1 = *v * c.beta2 + c.one_minus_beta2 * (g * g);
+    *m = m1;
+    *v = v1;
+    const float denom = sqrtf(v1) / c.bc2_sqrt + c.eps;
+    return p + (-c.step_size) * (m1 / denom);
+}
+
 // ---------------------------------------------------------------- covariance
 
 // forward.cu:114-148.  q = (r, x, y, z), used as given (not normalised).

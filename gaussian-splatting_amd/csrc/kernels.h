@@ -90,6 +90,9 @@ hipError_t launch_render_bwd(const GsrScene& s, const GeomBuf& g, const ImageVie
 hipError_t launch_preprocess_bwd(const GsrScene& s, const int* radii, const GeomBuf& g, const GsrBackwardIO& io,
                                  const GradRec* acc, hipStream_t st);
 
+hipError_t launch_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible,
+                       int64_t N, int M, const AdamConst& c, hipStream_t st);
+
 hipError_t launch_knn(int P, const float* points, float* out, void* temp, hipStream_t st);
 size_t knn_temp_bytes(int P);
 

@@ -1,0 +1,62 @@
+// Fused Adam step over one parameter tensor of the Gaussians ([N, M] floats,
+// row = Gaussian): parameter, gradient and both moments are read once and the
+// parameter and moments written once (28 bytes per element), rows of Gaussians
+// that are not flagged visible are skipped without being read.
+//
+// The reference optimises with torch.optim.Adam (scene/gaussian_model.py:112-113)
+// and tries to import a sparse variant, SparseGaussianAdam(params, lr, eps)
+// .step(visibility, N), from the rasterizer package (train.py:38-42, 339-343);
+// that class lives in graphdeco-inria/diff-gaussian-rasterization (branch
+// 3dgs_accel), which the fork does not vendor.  Its published update is Adam
+// without bias correction on the visible rows only.
+#include "kernels.h"
+
+namespace gs {
+
+template <int VEC>
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                   float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
+                                                   const uint8_t* __restrict__ visible, int64_t total, int M,
+                                                   const AdamConst c) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (i >= total) return;
+    if (visible && !visible[i / M]) return;  // VEC divides M, so the VEC elements share a row
+    if (VEC == 4) {
+        float4 p = *reinterpret_cast<float4*>(param + i);
+        const float4 g = *reinterpret_cast<const float4*>(grad + i);
+        float4 m = *reinterpret_cast<float4*>(exp_avg + i);
+        float4 v = *reinterpret_cast<float4*>(exp_avg_sq + i);
+        p.x = adam_update(p.x, g.x, &m.x, &v.x, c);
+        p.y = adam_update(p.y, g.y, &m.y, &v.y, c);
+        p.z = adam_update(p.z, g.z, &m.z, &v.z, c);
+        p.w = adam_update(p.w, g.w, &m.w, &v.w, c);
+        *reinterpret_cast<float4*>(param + i) = p;
+        *reinterpret_cast<float4*>(exp_avg + i) = m;
+        *reinterpret_cast<float4*>(exp_avg_sq + i) = v;
+    } else {
+        float m = exp_avg[i], v = exp_avg_sq[i];
+        param[i] = adam_update(param[i], grad[i], &m, &v, c);
+        exp_avg[i] = m;
+        exp_avg_sq[i] = v;
+    }
+}
+
+hipError_t launch_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible,
+                       int64_t N, int M, const AdamConst& c, hipStream_t st) {
+    const int64_t total = N * M;
+    if (total <= 0) return hipSuccess;
+    // 16-byte accesses when they cannot straddle a row (sparse) or always (dense); tensors are 16-byte aligned
+    const bool vec = visible ? (M % 4 == 0) : (total % 4 == 0);
+    const bool aligned = (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0;
+    if (vec && aligned) {
+        const int64_t threads = total / 4;
+        hipLaunchKernelGGL(adam_kernel<4>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, param, grad,
+                           exp_avg, exp_avg_sq, visible, total, M, c);
+    } else {
+        hipLaunchKernelGGL(adam_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, param, grad, exp_avg,
+                           exp_avg_sq, visible, total, M, c);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace gs

@@ -202,6 +202,20 @@ int gss_ssim_backward(int B, int CH, int H, int W, float C1, float C2, const flo
                       const float* dL_dmap, float* dL_dimg1, const float* dm_dmu1, const float* dm_dsigma1_sq,
                       const float* dm_dsigma12, void* stream);
 
+/* Fused Adam step over one parameter tensor [N, M] (row = Gaussian), in place.
+ * Replaces, for the model's parameter groups, torch.optim.Adam as configured at
+ * scene/gaussian_model.py:112-113 (same operation order as its single-tensor path) and provides
+ * the sparse step the reference looks for at train.py:38-42, 339-343
+ * (SparseGaussianAdam.step(visibility, N) of graphdeco-inria/diff-gaussian-rasterization, branch
+ * 3dgs_accel: not vendored by the fork; Adam without bias correction on the visible rows).
+ *   visible: device [N] bytes, nonzero = update the row; NULL = every row.
+ *   bias_correction1 = 1 - beta1^step, bias_correction2_sqrt = sqrt(1 - beta2^step); pass 1, 1 for
+ *   the sparse variant.  The scalars are doubles because torch forms 1 - beta, lr / bias_correction1
+ *   in double before rounding to float, and so does this call. */
+int gso_adam_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible,
+                    int64_t N, int M, double lr, double beta1, double beta2, double eps, double bias_correction1,
+                    double bias_correction2_sqrt, void* stream);
+
 const char* gsr_status_string(int status);
 
 #ifdef __cplusplus

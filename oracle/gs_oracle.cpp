@@ -607,6 +607,19 @@ void gso_activate_bwd(int P, const float* logit, const float* logscale, const fl
     }
 }
 
+// Adam step over one [N, M] tensor (torch.optim.Adam's single-tensor operation
+// order; visible == NULL updates every row), for checking the fused kernel.
+void gso_adam_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible,
+                     int64_t N, int M, double lr, double beta1, double beta2, double eps, double bc1, double bc2_sqrt) {
+    const AdamConst c = adam_const(lr, beta1, beta2, eps, bc1, bc2_sqrt);
+#pragma omp parallel for
+    for (int64_t r = 0; r < N; ++r) {
+        if (visible && !visible[r]) continue;
+        for (int64_t i = r * M; i < (r + 1) * M; ++i)
+            param[i] = adam_update(param[i], grad[i], &exp_avg[i], &exp_avg_sq[i], c);
+    }
+}
+
 // ------------------------------------------------------------------ simple-knn
 
 // stride > 1: only every stride-th point of the Morton order is searched (the

@@ -78,6 +78,7 @@ def lib():
         _lib.gso_sh_eval.argtypes = [C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _bp]
         _lib.gso_activate.argtypes = [C.c_int] + [_fp] * 6
         _lib.gso_activate_bwd.argtypes = [C.c_int] + [_fp] * 6
+        _lib.gso_adam_update.argtypes = [_fp, _fp, _fp, _fp, _bp, C.c_int64, C.c_int] + [C.c_double] * 6
         _lib.gso_dist2.argtypes = [C.c_int, _fp, _fp]
         _lib.gso_dist2_strided.argtypes = [C.c_int, _fp, _fp, C.c_int]
         _lib.gso_ssim_fwd.argtypes = [C.c_int] * 4 + [C.c_float] * 2 + [_fp] * 6
@@ -279,6 +280,21 @@ def activate_bwd(opacity_logit, log_scaling, rotation_raw, g_opacity, g_scales, 
     go = go.reshape(-1)
     lib().gso_activate_bwd(ls.shape[0], _f(lo), _f(ls), _f(rr), _f(go), _f(gs), _f(gr))
     return go, gs, gr
+
+
+def adam_update(param, grad, exp_avg, exp_avg_sq, visible, lr, beta1, beta2, eps, step=0):
+    """One Adam step on copies of the [N, M] arrays; step = 0: no bias correction
+    (the sparse variant).  Returns (param, exp_avg, exp_avg_sq)."""
+    p, m, v = (np.array(a, np.float32, copy=True, order="C") for a in (param, exp_avg, exp_avg_sq))
+    g = _c(grad)
+    N = p.shape[0]
+    M = int(p.size // max(N, 1))
+    bc1 = 1.0 - beta1 ** step if step > 0 else 1.0
+    bc2s = float(np.sqrt(1.0 - beta2 ** step)) if step > 0 else 1.0
+    vis = None if visible is None else np.ascontiguousarray(visible, np.uint8)
+    lib().gso_adam_update(_f(p), _f(g), _f(m), _f(v), None if vis is None else vis.ctypes.data_as(_bp), N, M, lr, beta1,
+                          beta2, eps, bc1, bc2s)
+    return p, m, v
 
 
 def sh_eval(deg, pos, campos, shs):

@@ -1,0 +1,102 @@
+"""GPU parity of the fused Adam step: bit-exact against the CPU checker (same
+arithmetic, shared header), close to torch.optim.Adam (which forms its bias
+corrections in double precision), and a drop-in for it as far as the
+reference's optimizer-state surgery is concerned."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_update(p, g, m, v, vis, lr, b1, b2, eps, step):
+    from _gsplat_lib import check, lib
+    t = lambda a: torch.tensor(a, device="cuda:0")
+    tp, tg, tm, tv = t(p), t(g), t(m), t(v)
+    tvis = None if vis is None else torch.tensor(vis.astype(np.uint8), device="cuda:0")
+    N = p.shape[0]
+    M = p.size // max(N, 1)
+    bc1 = 1.0 - b1 ** step if step > 0 else 1.0
+    bc2s = float(np.sqrt(1.0 - b2 ** step)) if step > 0 else 1.0
+    check(lib().gso_adam_update(tp.data_ptr(), tg.data_ptr(), tm.data_ptr(), tv.data_ptr(),
+                                None if tvis is None else tvis.data_ptr(), N, M, lr, b1, b2, eps, bc1, bc2s,
+                                torch.cuda.current_stream().cuda_stream), "adam")
+    torch.cuda.synchronize()
+    return tp.cpu().numpy(), tm.cpu().numpy(), tv.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1000, 3), (777, 4), (513, 15, 3), (4097, 1), (300, 1, 3)])
+@pytest.mark.parametrize("sparse", [False, True], ids=["dense", "sparse"])
+def test_adam_matches_checker_bit_for_bit(oracle, shape, sparse):
+    rng = np.random.default_rng(sum(shape))
+    p = rng.standard_normal(shape).astype(np.float32)
+    m = (rng.standard_normal(shape) * 0.1).astype(np.float32)
+    v = (rng.standard_normal(shape) ** 2 * 0.01).astype(np.float32)
+    vis = (rng.random(shape[0]) < 0.6) if sparse else None
+    for step in (1, 2, 7):
+        g = rng.standard_normal(shape).astype(np.float32)
+        st = 0 if sparse else step
+        rp, rm, rv = oracle.adam_update(p, g, m, v, vis, 1.6e-4, 0.9, 0.999, 1e-15, st)
+        gp, gm, gv = _gpu_update(p, g, m, v, vis, 1.6e-4, 0.9, 0.999, 1e-15, st)
+        assert np.array_equal(gp, rp) and np.array_equal(gm, rm) and np.array_equal(gv, rv)
+        if sparse:
+            assert np.array_equal(gp[~vis], p[~vis]) and np.array_equal(gm[~vis], m[~vis])
+        p, m, v = gp, gm, gv
+
+
+def test_optimizer_class_against_torch_adam():
+    from gsplat_optim import FusedGaussianAdam
+    rng = np.random.default_rng(3)
+    shapes = {"xyz": (2000, 3), "f_dc": (2000, 1, 3), "f_rest": (2000, 15, 3), "opacity": (2000, 1), "scaling": (2000, 3),
+              "rotation": (2000, 4), "reps": (2000, 4)}
+    lrs = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=1.25e-4, opacity=2.5e-2, scaling=5e-3, rotation=1e-3, reps=1e-2)
+    init = {k: rng.standard_normal(s).astype(np.float32) for k, s in shapes.items()}
+
+    def make(cls):
+        ps = {k: torch.nn.Parameter(torch.tensor(v, device="cuda:0")) for k, v in init.items()}
+        groups = [{"params": [ps[k]], "lr": lrs[k], "name": k} for k in shapes]
+        return ps, cls(groups, lr=0.0, eps=1e-15)
+
+    pa, oa = make(torch.optim.Adam)
+    pb, ob = make(FusedGaussianAdam)
+    for step in range(5):
+        for k in shapes:
+            g = torch.tensor(rng.standard_normal(shapes[k]).astype(np.float32), device="cuda:0")
+            pa[k].grad = g.clone()
+            pb[k].grad = g.clone()
+        if step == 2:   # the scheduler changes the position learning rate every iteration (gaussian_model.py:186-195)
+            for o in (oa, ob):
+                for grp in o.param_groups:
+                    if grp["name"] == "xyz":
+                        grp["lr"] = 1.1e-4
+        oa.step()
+        ob.step()
+    for k in shapes:
+        a, b = pa[k].detach().cpu().numpy(), pb[k].detach().cpu().numpy()
+        assert np.abs(a - b).max() <= 2e-6 * max(1.0, np.abs(a).max()), k
+        sa, sb = oa.state[pa[k]], ob.state[pb[k]]
+        assert set(sb.keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sb["step"]) == 5.0
+        assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-7)
+        assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+    # the state surgery of densification: replace a tensor and keep (masked) moments, as _prune_optimizer does
+    mask = torch.arange(2000, device="cuda:0") % 3 != 0
+    for grp in ob.param_groups:
+        old = grp["params"][0]
+        st = ob.state.pop(old)
+        st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"][mask], st["exp_avg_sq"][mask]
+        new = torch.nn.Parameter(old[mask].detach().clone())
+        grp["params"][0] = new
+        ob.state[new] = st
+        new.grad = torch.ones_like(new)
+    ob.step()
+    sd = ob.state_dict()
+    assert len(sd["state"]) == len(shapes)
+    # sparse step: only visible rows move, parameter groups that are not per-Gaussian are left alone
+    n = int(mask.sum())
+    vis = torch.rand(n, device="cuda:0") < 0.5
+    before = {grp["name"]: grp["params"][0].detach().clone() for grp in ob.param_groups}
+    ob.step(vis, n)
+    for grp in ob.param_groups:
+        p, b = grp["params"][0].detach(), before[grp["name"]]
+        assert torch.equal(p[~vis], b[~vis])
+        assert not torch.equal(p[vis], b[vis])

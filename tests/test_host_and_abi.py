@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     src = open(os.path.join(ROOT, "include", "gsplat_amd.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(g(?:sr|sk|ss)_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(g(?:sr|sk|ss|so)_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():
