@@ -196,11 +196,15 @@ __device__ __forceinline__ void pre_bwd_rendered(const PreBwdArgs& a, size_t i, 
     a.dL_dmeans2D[3 * i] = g0.x;
     a.dL_dmeans2D[3 * i + 1] = g0.y;
     a.dL_dmeans2D[3 * i + 2] = 0.f;
-    a.dL_dcolors[3 * i] = g1.z;
-    a.dL_dcolors[3 * i + 1] = g1.w;
-    a.dL_dcolors[3 * i + 2] = g2.x;
+    if (a.dL_dcolors) {
+        a.dL_dcolors[3 * i] = g1.z;
+        a.dL_dcolors[3 * i + 1] = g1.w;
+        a.dL_dcolors[3 * i + 2] = g2.x;
+    }
+    if (a.dL_dcov3D) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) a.dL_dcov3D[6 * i + k] = dcov6[k];
+        for (int k = 0; k < 6; ++k) a.dL_dcov3D[6 * i + k] = dcov6[k];
+    }
     if (accum) {
         a.dL_dopacity[i] += dop;
         a.dL_dmeans3D[3 * i] += dmean.x;
@@ -224,9 +228,11 @@ __device__ __forceinline__ void pre_bwd_rendered(const PreBwdArgs& a, size_t i, 
 template <int MODE>
 __device__ __forceinline__ void pre_bwd_unrendered(const PreBwdArgs& a, size_t i, float* lds, int lane) {
     a.dL_dmeans2D[3 * i] = a.dL_dmeans2D[3 * i + 1] = a.dL_dmeans2D[3 * i + 2] = 0.f;
-    a.dL_dcolors[3 * i] = a.dL_dcolors[3 * i + 1] = a.dL_dcolors[3 * i + 2] = 0.f;
+    if (a.dL_dcolors) a.dL_dcolors[3 * i] = a.dL_dcolors[3 * i + 1] = a.dL_dcolors[3 * i + 2] = 0.f;
+    if (a.dL_dcov3D) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) a.dL_dcov3D[6 * i + k] = 0.f;
+        for (int k = 0; k < 6; ++k) a.dL_dcov3D[6 * i + k] = 0.f;
+    }
     if (MODE == SH_SPLIT16) {  // also when accumulating: a 16-byte chunk can straddle a rendered neighbour's row
 #pragma unroll
         for (int k = 0; k < REST_ROW_F; ++k) lds[lane * REST_ROW_F + k] = 0.0f;

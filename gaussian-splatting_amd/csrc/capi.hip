@@ -145,7 +145,10 @@ int gsr_backward(const GsrScene* s, const int* radii, const void* geom_buffer, c
     if (!io) return GSR_ERR_ARG;
     if (s->P == 0) return GSR_OK;
     if (!radii || !geom_buffer || !image_buffer || !io->dL_dout_color || !io->work) return GSR_ERR_ARG;
-    if (!io->dL_dmeans2D || !io->dL_dcolors || !io->dL_dopacity || !io->dL_dmeans3D || !io->dL_dcov3D) return GSR_ERR_ARG;
+    if (!io->dL_dmeans2D || !io->dL_dopacity || !io->dL_dmeans3D) return GSR_ERR_ARG;
+    // the two intermediate gradients are only outputs when the matching precomputed input was given
+    if (s->colors_precomp && !io->dL_dcolors) return GSR_ERR_ARG;
+    if (s->cov3D_precomp && !io->dL_dcov3D) return GSR_ERR_ARG;
     if (s->M > 0 && s->shs && !io->dL_dsh) return GSR_ERR_ARG;
     if (s->shs_rest && !io->dL_dsh_rest) return GSR_ERR_ARG;
     if (s->scales && (!io->dL_dscales || !io->dL_drotations)) return GSR_ERR_ARG;

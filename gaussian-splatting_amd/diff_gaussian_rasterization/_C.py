@@ -142,8 +142,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
                 return t
             return torch.zeros(shape, **f32) if fill_zero else e(shape, **f32)
 
-        dL_dmeans3D, dL_dmeans2D, dL_dcolors = buf("means3D", (P, 3)), e((P, 3), **f32), e((P, 3), **f32)
-        dL_dopacity, dL_dcov3D = buf("opacity", (P, 1)), e((P, 6), **f32)
+        # the two intermediate gradients are not stored when the caller writes into its own buffers
+        # (forward_params never returns them)
+        lean = bool(into) and raw_params
+        dL_dmeans3D, dL_dmeans2D = buf("means3D", (P, 3)), e((P, 3), **f32)
+        dL_dcolors = None if lean else e((P, 3), **f32)
+        dL_dopacity, dL_dcov3D = buf("opacity", (P, 1)), (None if lean else e((P, 6), **f32))
         dL_dsh = buf("sh", (P, 1 if split else M, 3))
         dL_dsh_rest = buf("sh_rest", (P, M - 1, 3)) if split else None
         dL_dscales = buf("scales", (P, 3), not has_sr)

@@ -131,10 +131,10 @@ typedef struct {
     const float* dL_dout_invdepth;  /* device [H,W] or NULL */
     const float* dL_dout_reps;      /* device [DIM,H,W] or NULL iff DIM == 0 */
     float* dL_dmeans2D;      /* device [P,3] (z stays 0) */
-    float* dL_dcolors;       /* device [P,3] */
+    float* dL_dcolors;       /* device [P,3]; may be NULL unless colors_precomp was given (then it is not stored) */
     float* dL_dopacity;      /* device [P] */
     float* dL_dmeans3D;      /* device [P,3] */
-    float* dL_dcov3D;        /* device [P,6] */
+    float* dL_dcov3D;        /* device [P,6]; may be NULL unless cov3D_precomp was given */
     float* dL_dsh;           /* device [P,M,3] or NULL iff M == 0 */
     float* dL_dscales;       /* device [P,3] or NULL iff scales == NULL */
     float* dL_drotations;    /* device [P,4] or NULL iff rotations == NULL */
