@@ -175,12 +175,16 @@ def cpu_baseline(P_full, W, H, seed):
                       f"of the OpenMP checker took {dt:.2f} s"}
 
 
-def load_pmc_traffic():
-    """HBM bytes per launch from the rocprofv3 --pmc passes of this command, if a summary was committed."""
+def load_pmc_traffic(P, W, H):
+    """HBM bytes per launch from the rocprofv3 --pmc passes of this command, if a summary was
+    committed for this workload (the counters cannot be read from inside the process)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)
+            d = json.load(f)
+        if d.get("_workload") != [P, W, H]:
+            return {}
+        return {k: v for k, v in d.items() if not k.startswith("_")}
     except Exception:
         return {}
 
@@ -206,11 +210,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}")
-    dev = torch.device(f"cuda:{local_rank}")
+    # one rank per GPU; for rehearsing the multi-rank path on a box with fewer GPUs the ranks wrap around the
+    # devices and GSPLAT_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
+    dev = torch.device(f"cuda:{local_rank % max(1, torch.cuda.device_count())}")
     torch.cuda.set_device(dev)
     import torch.distributed as dist
+    backend = os.environ.get("GSPLAT_BENCH_BACKEND", "nccl")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import synth
     import gsdp
@@ -265,6 +275,7 @@ def main():
         return out
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -281,7 +292,7 @@ def main():
     dt = time.perf_counter() - t0
     timer.arm(None)
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -357,7 +368,7 @@ def main():
             del opt
 
     if rank == 0:
-        traffic = load_pmc_traffic()
+        traffic = load_pmc_traffic(P, W, H)
         per_kernel = {}
         for k, ms in kernels.items():
             ab = algorithmic_bytes(k, P, visible, R, H * W, passes)
@@ -387,7 +398,8 @@ def main():
                                     "gradient all-reduce when n_gpus > 1; no optimizer"),
                        "api": "forward_params (raw parameters)" if use_params else "reference signature",
                        "gaussians": P, "views_per_gpu_per_step": V, "visible_mean": visible, "num_rendered_mean": R,
-                       "image": [W, H], "parallelism": f"view-sharded x{world}, full replicas" if world > 1 else "single GPU"},
+                       "image": [W, H], "parallelism": f"view-sharded x{world}, full replicas" if world > 1 else "single GPU",
+                       "collective_backend": (backend if world > 1 else None)},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic.get(dom),
                          "algorithmic_bytes_per_launch": ab, "ms_per_launch": kernels[dom],

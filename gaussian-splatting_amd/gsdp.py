@@ -39,7 +39,14 @@ class GradReducer:
     def start(self, tensors):
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return self
+        staged = dist.get_backend(self.group) == "gloo"
         for t in sorted((t for t in tensors if t is not None), key=lambda t: -t.numel()):
+            if staged and t.is_cuda:
+                # gloo rehearsal of the multi-rank path on GPU tensors: through host memory, synchronously
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+                continue
             self.pending.append((t, dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
         return self
 

@@ -67,8 +67,11 @@ def main():
     with open(os.path.join(ROOT, "profiles", "pmc_traffic_detail.json"), "w") as f:
         json.dump({k: traffic[k] for k in sorted(traffic)}, f, indent=1)
     simple = {k: v for k, v in traffic.items() if ":" not in k}
+    out_d = {k: simple[k] for k in sorted(simple)}
+    out_d["_workload"] = [6000000, 1920, 1080]   # bench.py defaults, which tools/collect_pmc.sh runs
+    out_d["_note"] = "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB, mean over the launches of the PMC passes"
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
-        json.dump({k: simple[k] for k in sorted(simple)}, f, indent=1)
+        json.dump(out_d, f, indent=1)
     print("wrote profiles/pmc_traffic.json", simple)
     # kernel stats of the trace pass
     stats = sorted(glob.glob(os.path.join(SRC, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
