@@ -1,0 +1,115 @@
+"""GPU parity on the corner cases of the operator's argument space: scale
+modifier, active SH degree below the allocated one, one Gaussian, a splat
+covering the whole image, images smaller than a tile and not multiples of 16,
+everything culled.  Same bars as the main parity tests."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from gpu_util import read_internals, rel_err, run_forward_raw, scene_to_torch
+from test_gpu_rasterizer import ABS_TOL, REL_TOL, _grads_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(oracle, sc, rs, ten, aa, bg, scale_modifier=1.0, sh_degree=None, backward=True):
+    P, W, H = ten["means3D"].shape[0], rs.image_width, rs.image_height
+    f = oracle.forward_from_scene(sc, bg=bg, antialiasing=aa, scale_modifier=scale_modifier, sh_degree=sh_degree)
+    out = run_forward_raw(rs, ten)
+    torch.cuda.synchronize()
+    it = read_internals(out, P, W, H)
+    assert out["num_rendered"] == f.R
+    assert np.array_equal(out["radii"].cpu().numpy(), f.radii)
+    assert np.array_equal(it["keys"], f.keys)
+    assert np.array_equal(it["point_list"], f.point_list)
+    assert np.array_equal(it["ranges"], f.ranges)
+    assert np.array_equal(it["n_contrib"], f.n_contrib)
+    assert np.array_equal(out["gauss_count"].cpu().numpy(), f.gauss_count)
+    assert np.array_equal(out["last_contr_gauss"].cpu().numpy(), f.last_contr)
+    assert np.abs(out["color"].cpu().numpy() - f.out_color).max() <= ABS_TOL
+    assert np.abs(out["invdepth"].cpu().numpy() - f.invdepth).max() <= ABS_TOL
+    assert np.abs(out["out_reps"].cpu().numpy() - f.out_reps).max() <= ABS_TOL * 10
+    if not backward:
+        return f, out
+    rng = np.random.default_rng(P + W)
+    gc = rng.standard_normal((3, H, W)).astype(np.float32)
+    gd = rng.standard_normal((1, H, W)).astype(np.float32)
+    gr = rng.standard_normal((4, H, W)).astype(np.float32)
+    ref = f.backward(gc, gd, gr)
+    t = lambda a: torch.tensor(a, device="cuda:0")
+    got = _grads_gpu(rs, ten, t(gc), t(gd), t(gr), {}, out)
+    for k in got:
+        r = ref[k].reshape(got[k].shape)
+        assert np.isfinite(got[k]).all(), k
+        assert rel_err(got[k], r) <= REL_TOL, (k, rel_err(got[k], r))
+    return f, out
+
+
+@pytest.mark.parametrize("mod", [0.5, 1.7])
+def test_scale_modifier(oracle, mod):
+    sc = synth.tiny_scene(P=300, width=96, height=64, seed=41)
+    rs, ten = scene_to_torch(sc, bg=(0.2, 0.4, 0.6), antialiasing=True, scale_modifier=mod)
+    _compare(oracle, sc, rs, ten, True, (0.2, 0.4, 0.6), scale_modifier=mod)
+
+
+@pytest.mark.parametrize("degree", [0, 1, 2])
+def test_active_degree_below_allocated(oracle, degree):
+    """The model starts at degree 0 with 16 coefficients allocated (train.py:146-147): the inactive
+    coefficients must neither colour the image nor receive gradient."""
+    sc = synth.tiny_scene(P=300, width=80, height=48, seed=43)
+    sc["sh_degree"] = degree
+    rs, ten = scene_to_torch(sc, antialiasing=False)
+    f, out = _compare(oracle, sc, rs, ten, False, (0.0, 0.0, 0.0), sh_degree=degree)
+    H, W = rs.image_height, rs.image_width
+    gc = torch.ones((3, H, W), device="cuda:0")
+    gr = torch.zeros((4, H, W), device="cuda:0")
+    got = _grads_gpu(rs, ten, gc, None, gr, {}, out)
+    n = (degree + 1) ** 2
+    assert np.all(got["dL_dsh"][:, n:] == 0)
+
+
+@pytest.mark.parametrize("W,H", [(7, 5), (16, 16), (17, 33), (250, 3)])
+def test_small_and_ragged_images(oracle, W, H):
+    sc = synth.tiny_scene(P=120, width=W, height=H, seed=47, scale=0.3)
+    rs, ten = scene_to_torch(sc, bg=(1.0, 0.0, 0.5), antialiasing=True)
+    _compare(oracle, sc, rs, ten, True, (1.0, 0.0, 0.5))
+
+
+def test_single_gaussian_and_full_screen_splat(oracle):
+    sc = synth.tiny_scene(P=1, width=64, height=48, seed=51)
+    rs, ten = scene_to_torch(sc, antialiasing=False)
+    _compare(oracle, sc, rs, ten, False, (0.0, 0.0, 0.0))
+    # one enormous, nearly opaque splat in front of many small ones: touches every tile
+    sc = synth.tiny_scene(P=200, width=160, height=96, seed=53)
+    sc["scales"][0] = 50.0
+    sc["opacities"].reshape(-1)[0] = 0.99
+    sc["means3D"][0] = sc["means3D"].mean(axis=0)
+    rs, ten = scene_to_torch(sc, antialiasing=True)
+    f, out = _compare(oracle, sc, rs, ten, True, (0.0, 0.0, 0.0))
+    tiles = ((160 + 15) // 16) * ((96 + 15) // 16)
+    it = read_internals(out, 200, 160, 96)
+    assert it["bin"][0, 3] == tiles or f.radii[0] == 0
+
+
+def test_everything_culled(oracle):
+    sc = synth.tiny_scene(P=64, width=48, height=32, seed=57)
+    sc["means3D"][:, 2] = -np.abs(sc["means3D"][:, 2]) - 50.0     # behind the camera wherever it looks from
+    cam = sc["camera"]
+    view = np.asarray(cam["viewmatrix"], np.float32)
+    # move the points to the far side along the camera's viewing axis
+    z_axis = view[:3, 2]
+    sc["means3D"] = (np.asarray(cam["campos"], np.float32)[None] - 10.0 * z_axis[None] +
+                     0.1 * sc["means3D"]).astype(np.float32)
+    rs, ten = scene_to_torch(sc, bg=(0.3, 0.3, 0.3), antialiasing=False)
+    f = oracle.forward_from_scene(sc, bg=(0.3, 0.3, 0.3))
+    out = run_forward_raw(rs, ten)
+    assert f.R == 0 and out["num_rendered"] == 0
+    assert np.array_equal(out["radii"].cpu().numpy(), f.radii)
+    assert np.abs(out["color"].cpu().numpy() - f.out_color).max() <= ABS_TOL
+    assert (out["last_contr_gauss"].cpu().numpy() == -1).all()
+    H, W = rs.image_height, rs.image_width
+    got = _grads_gpu(rs, ten, torch.ones((3, H, W), device="cuda:0"), None, torch.ones((4, H, W), device="cuda:0"),
+                     {}, out)
+    for k, v in got.items():
+        assert np.all(v == 0), k
