@@ -105,7 +105,7 @@ class KernelTimer:
 
     PAIRS = {"preprocess": (0, 1), "scan": (1, 2), "depth_order": (3, 4), "emit_keys": (4, 5), "sort": (5, 6),
              "tile_ranges": (6, 7), "render_fwd": (7, 8), "finish_stats": (8, 9), "bwd_clear": (10, 11),
-             "render_bwd": (11, 12), "preprocess_bwd": (12, 13)}
+             "render_bwd": (11, 12), "preprocess_bwd": (12, 13), "preprocess_bwd_batch": (14, 15)}
 
     def __init__(self, sets):
         import _gsplat_lib as G
@@ -121,12 +121,18 @@ class KernelTimer:
     def arm(self, i):
         self.G.set_profile_events(self.arrays[i] if i is not None else None)
 
-    def means_ms(self, fwd_only=False):
+    def means_ms(self, fwd_only=False, batch_sets=None):
+        """batch_sets: indices of the event sets that were armed when a batched backward ran."""
         out = {}
         for k, (a, b) in self.PAIRS.items():
             if fwd_only and a >= 10:
                 continue
-            out[k] = float(np.mean([row[a].elapsed_time(row[b]) for row in self.events]))
+            rows = self.events
+            if a >= 14:
+                if not batch_sets:
+                    continue
+                rows = [self.events[i] for i in batch_sets]
+            out[k] = float(np.mean([row[a].elapsed_time(row[b]) for row in rows]))
         return out
 
 
@@ -145,12 +151,13 @@ def algorithmic_bytes(kernel, P, visible, R, HW, passes):
         "render_fwd": 28.0 * R + 48.0 * HW,
         "render_bwd": 60.0 * R + 40.0 * HW + 56.0 * R,
         "preprocess_bwd": 575.0 * visible,
+        "preprocess_bwd_batch": 575.0 * visible,   # per view of the batch; bench scales it by the views per launch
     }.get(kernel)
 
 
 # What bounds each kernel (the blend kernels stop early per pixel and are limited by
 # VALU / LDS issue, not by the bytes they move; the others stream through HBM).
-BOUND = {"preprocess": "hbm", "depth_order": "hbm", "emit_keys": "hbm", "sort": "hbm", "tile_ranges": "hbm",
+BOUND = {"preprocess_bwd_batch": "hbm", "preprocess": "hbm", "depth_order": "hbm", "emit_keys": "hbm", "sort": "hbm", "tile_ranges": "hbm",
          "render_fwd": "valu+lds", "render_bwd": "valu+lds+atomics", "preprocess_bwd": "hbm"}
 
 
@@ -200,6 +207,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--api", choices=("params", "reference"), default="params",
                     help="params: forward_params (raw parameters); reference: unchanged reference signature")
+    ap.add_argument("--no-defer", action="store_true",
+                    help="run the per-Gaussian backward after every view instead of once per step for all its views")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-view / reference-API / FPS measurements")
     ap.add_argument("--fwd-only", action="store_true", help="time rendering only (render FPS)")
@@ -241,7 +250,7 @@ def main():
         views.append((make_settings(cam, dev, sh_degree), gt))
     leaves = list(params.values())
     use_params = args.api == "params"
-    sink = ParamGradSink(*leaves) if use_params else None
+    sink = ParamGradSink(*leaves, defer=not args.no_defer) if use_params else None
     log(f"[rank {rank}] scene ready in {time.time() - t0:.1f}s")
 
     def one_view(rs, gt):
@@ -265,6 +274,8 @@ def main():
             if timer is not None:
                 timer.arm(k * V + v)
             out = one_view(rs, gt)
+        if use_params and not args.fwd_only:
+            sink.flush()   # deferred mode: the per-Gaussian backward of all V views, once
         if world > 1 and not args.fwd_only:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -280,23 +291,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # W untimed warm-up steps; the allocator and the HIP runtime only reach their steady state in the third
+    # step of a process (one slow step shows up there whatever W is), so at least three untimed steps are run
+    for _ in range(max(args.warmup, 3)):
         out = step()
     sync()
     timer = KernelTimer(args.steps * V)
     sync()
     t0 = time.perf_counter()
+    marks = []
     for k in range(args.steps):
         out = step(k, timer)
+        marks.append(time.perf_counter())   # host-side launch progress (no sync): shows when the host is the limit
     sync()
     dt = time.perf_counter() - t0
+    log(f"[rank {rank}] host launch time per step (ms): " +
+        " ".join(f"{(b - a) * 1e3:.1f}" for a, b in zip([t0] + marks[:-1], marks)))
     timer.arm(None)
     if world > 1:
         tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    kernels = timer.means_ms(args.fwd_only)
+    deferred = use_params and sink.defer and not args.fwd_only
+    kernels = timer.means_ms(args.fwd_only, [k * V + V - 1 for k in range(args.steps)] if deferred else None)
+    if deferred:
+        kernels["means2d_grad"] = kernels.pop("preprocess_bwd")   # in deferred mode that slot times the gradient copy
     gx, gy = (W + 15) // 16, (H + 15) // 16
     passes = ((gx * gy).bit_length() + 7) // 8   # the instance sort only orders the tile bits
 
@@ -332,6 +352,7 @@ def main():
             sink.begin_step() if use_params else None
             o = render_params(params, rs0, sink)
             train_loss(o, gt0).backward()
+            sink.flush()
 
         def it_reference():
             for p in leaves:
@@ -370,17 +391,25 @@ def main():
     if rank == 0:
         traffic = load_pmc_traffic(P, W, H)
         per_kernel = {}
-        for k, ms in kernels.items():
+        launches = lambda k: 1 if k == "preprocess_bwd_batch" else V          # per step
+        units = lambda k: V if k == "preprocess_bwd_batch" else 1             # views one launch works for
+
+        def alg(k):
             ab = algorithmic_bytes(k, P, visible, R, H * W, passes)
-            ent = {"ms": ms}
+            return ab * units(k) if ab else None
+
+        for k, ms in kernels.items():
+            ab = alg(k)
+            ent = {"ms": ms, "launches_per_step": launches(k)}
             if ab:
                 ent.update({"algorithmic_GBps": ab / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                             "bound": BOUND.get(k)})
                 if k in traffic:
                     ent["hbm_traffic_bytes"] = traffic[k]
             per_kernel[k] = ent
-        dom = max((k for k in kernels if algorithmic_bytes(k, P, visible, R, H * W, passes)), key=lambda k: kernels[k])
-        ab = algorithmic_bytes(dom, P, visible, R, H * W, passes)
+        # the kernel with the largest share of a step
+        dom = max((k for k in kernels if alg(k)), key=lambda k: kernels[k] * launches(k))
+        ab = alg(dom)
         achieved = ab / (kernels[dom] * 1e-3) / 1e9
         views_total = world * V * args.steps
         res = {

@@ -38,6 +38,12 @@ class GsrBackwardIO(C.Structure):
                [("work_bytes", C.c_size_t), ("dL_dsh_rest", _vp), ("accumulate", C.c_int)]
 
 
+class GsrBackwardView(C.Structure):
+    _fields_ = [("viewmatrix", _vp), ("projmatrix", _vp), ("campos", _vp), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("W", C.c_int), ("H", C.c_int), ("antialiasing", C.c_int), ("has_invdepth", C.c_int), ("radii", _vp),
+                ("geom_buffer", _vp), ("work", _vp)]
+
+
 class GsrLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("rec", "cov3D", "tiles", "clamped", "block_sums", "total", "final_T",
                                           "n_contrib", "ranges", "keys0", "keys1", "vals0", "vals1")] + \
@@ -73,6 +79,11 @@ def lib():
     L.gsr_forward_stage2.argtypes = [C.POINTER(GsrScene), C.POINTER(GsrForwardOut), C.c_int64, _vp, C.c_size_t, _vp]
     L.gsr_backward.restype = C.c_int
     L.gsr_backward.argtypes = [C.POINTER(GsrScene), _vp, _vp, _vp, _vp, C.c_int64, C.POINTER(GsrBackwardIO), _vp]
+    L.gsr_backward_blend.restype = C.c_int
+    L.gsr_backward_blend.argtypes = L.gsr_backward.argtypes
+    L.gsr_backward_geometry_batch.restype = C.c_int
+    L.gsr_backward_geometry_batch.argtypes = [C.POINTER(GsrScene), C.c_int, C.POINTER(GsrBackwardView),
+                                              C.POINTER(GsrBackwardIO), _vp]
     L.gsr_mark_visible.restype = C.c_int
     L.gsr_mark_visible.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _vp]
     L.gsr_sort_pairs_u64_u32.restype = C.c_int
@@ -99,14 +110,15 @@ def lib():
 
 
 EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backward_work_bytes",
-            "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_mark_visible", "gsr_sort_temp_bytes",
+            "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_backward_blend",
+            "gsr_backward_geometry_batch", "gsr_mark_visible", "gsr_sort_temp_bytes",
             "gsr_sort_pairs_u64_u32", "gsr_layout", "gsr_sorted_keys_u64", "gsk_dist2_temp_bytes", "gsk_dist2", "gss_ssim_forward",
             "gss_ssim_backward", "gso_adam_update", "gsr_status_string")
 
 
-NUM_PROFILE_EVENTS = 14
+NUM_PROFILE_EVENTS = 16
 EVENT_NAMES = ("stage1_begin", "preprocess", "scan", "stage2_begin", "depth_order", "emit", "sort", "ranges", "render",
-               "finish", "bwd_begin", "bwd_clear", "bwd_render", "bwd_preprocess")
+               "finish", "bwd_begin", "bwd_clear", "bwd_render", "bwd_preprocess", "batch_begin", "batch")
 
 # Optional per-thread hook used by bench.py: a ctypes array of hipEvent_t handles
 # that the next rasterizer calls record around their kernels.

@@ -341,6 +341,243 @@ __global__ void __launch_bounds__(256, PRE_BWD_WAVES) preprocess_bwd_kernel(cons
     }
 }
 
+// ------------------------------------------------------------------ several views at once
+// The per-Gaussian backward of a batch of views in one pass: the Gaussian's
+// parameters and SH row are read once, every view adds its share (its own
+// camera, radii, clamp flags and GradRec), and each gradient is written (or
+// added to the caller's buffer) once.  Per view this replaces 575 B of
+// traffic per visible Gaussian by the 64-byte GradRec plus 5 bytes of flags.
+// What is linear in the incoming gradients (3D covariance -> scale/rotation,
+// the activations' chain rule) is applied once to the sums.
+// SH layout: [P,1,3] + [P,15,3]; scales and rotations given (no precomputed
+// covariance); the other cases take the one-view path.
+constexpr int MAX_BATCH_VIEWS = 8;
+
+struct BatchView {
+    CamPtrs cam;
+    float tanx, tany;
+    int W, H, aa, has_invdepth;
+    const int* radii;
+    const uint8_t* clamped;
+    const GradRec* acc;
+};
+
+struct PreBwdBatchArgs {
+    PreBwdArgs a;  // parameters and outputs; its per-view members are unused
+    int nviews;
+    BatchView v[MAX_BATCH_VIEWS];
+};
+
+#ifndef PRE_BWD_BATCH_WAVES
+#define PRE_BWD_BATCH_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch_kernel(const PreBwdBatchArgs b) {
+    constexpr int WAVE_LDS = ShLds<SH_SPLIT16>::bytes_per_wave;
+    __shared__ __align__(16) char s_sh[4 * WAVE_LDS];
+    const PreBwdArgs& a = b.a;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wave_g0 = blockIdx.x * 256 + w * 64;
+    const int nrows = min(64, a.P - wave_g0);
+    if (nrows <= 0) return;
+    const bool live = idx < a.P;
+    const size_t i = (size_t)(live ? idx : 0);
+    float* lds = reinterpret_cast<float*>(s_sh + w * WAVE_LDS);
+    float* row = lds + lane * REST_ROW_F;
+
+    uint32_t seen = 0;  // bit v: rendered in view v
+    for (int v = 0; v < b.nviews; ++v)
+        if (live && b.v[v].radii[i] > 0) seen |= 1u << v;
+    const uint64_t rows = __ballot(seen != 0);
+    if (rows == 0 && a.accumulate) return;
+    if (rows) rest_rows_copy<0>(const_cast<float*>(a.shs_rest) + (size_t)wave_g0 * REST_ROW_F, lds, rows, nrows, lane);
+    wave_lds_sync();
+
+    V3 dmean = v3(0, 0, 0);
+    float dop = 0.f, ddc[3] = {0.f, 0.f, 0.f}, drep[4] = {0.f, 0.f, 0.f, 0.f};
+    float dcov6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    V3 sc = v3(1, 1, 1);
+    V4 q = {1, 0, 0, 0};
+    float dn = 1.0f, opac = 0.f;
+    if (seen) {
+        float shv[SH_ROW_F];
+        shv[0] = a.shs[3 * i];
+        shv[1] = a.shs[3 * i + 1];
+        shv[2] = a.shs[3 * i + 2];
+#pragma unroll
+        for (int k = 0; k < REST_ROW_F; ++k) shv[3 + k] = row[k];
+#pragma unroll
+        for (int k = 0; k < REST_ROW_F; ++k) row[k] = 0.0f;  // the row becomes the dL/dSH accumulator
+        const V3 mean = v3(a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]);
+        sc = v3(a.scales[3 * i], a.scales[3 * i + 1], a.scales[3 * i + 2]);
+        const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[i];
+        q = {q4.x, q4.y, q4.z, q4.w};
+        opac = a.opacities[i];
+        if (a.raw) {
+            sc = act_exp3(sc);
+            q = act_normalize4(q, &dn);
+            opac = act_sigmoid(opac);
+        }
+        float cov6[6];
+        cov3d_from_scale_rot(sc, a.mod, q, cov6);  // the same arithmetic as the forward: identical values
+        // Two sweeps over the views, so that the SH row (48 registers) is not live during the
+        // covariance chain: colour -> SH first, everything else second (the GradRec of a view is
+        // read in both; the second read comes from L2).
+        {
+            ShRegs sh = {shv};
+#pragma unroll 1
+            for (int v = 0; v < b.nviews; ++v) {
+                if (!((seen >> v) & 1u)) continue;
+                const BatchView& bv = b.v[v];
+                const float4* gq = reinterpret_cast<const float4*>(bv.acc + i);
+                const float4 g1 = gq[1];
+                const float g2x = gq[2].x;
+                const uint8_t cl = bv.clamped[i];
+                V3 gcol = v3(g1.z, g1.w, g2x);
+                gcol.x *= (cl & 1) ? 0 : 1;
+                gcol.y *= (cl & 2) ? 0 : 1;
+                gcol.z *= (cl & 4) ? 0 : 1;
+                auto out = [row, &ddc](int k, V3 g) {
+                    if (k == 0) {
+                        ddc[0] += g.x;
+                        ddc[1] += g.y;
+                        ddc[2] += g.z;
+                    } else {
+                        row[3 * k - 3] += g.x;
+                        row[3 * k - 2] += g.y;
+                        row[3 * k - 1] += g.z;
+                    }
+                };
+                const V3 campos = v3(bv.cam.campos[0], bv.cam.campos[1], bv.cam.campos[2]);
+                dmean = add(dmean, sh_to_rgb_bwd(a.D, mean, campos, gcol, sh, out));
+            }
+        }
+#pragma unroll 1
+        for (int v = 0; v < b.nviews; ++v) {
+            if (!((seen >> v) & 1u)) continue;
+            const BatchView& bv = b.v[v];
+            const Cam c = load_cam(bv.cam, bv.W, bv.H, bv.tanx, bv.tany, a.mod, a.D, a.M, bv.aa);
+            const float4* gq = reinterpret_cast<const float4*>(bv.acc + i);
+            const float4 g0 = gq[0], g1 = gq[1], g2 = gq[2], g3 = gq[3];
+            float dop_v = g1.y;
+            const float dinv = g2.y;
+            float dcov_v[6];
+            dmean = add(dmean, cov2d_bwd(c, mean, cov6, opac, v3(g0.z, g0.w, g1.x), &dop_v,
+                                         bv.has_invdepth ? &dinv : nullptr, dcov_v));
+            dmean = add(dmean, mean2d_bwd(mean, c.proj, g0.x, g0.y));
+            dop += dop_v;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dcov6[k] += dcov_v[k];
+            drep[0] += g2.z;
+            drep[1] += g2.w;
+            drep[2] += g3.x;
+            drep[3] += g3.y;
+        }
+    } else if (live) {
+#pragma unroll
+        for (int k = 0; k < REST_ROW_F; ++k) row[k] = 0.0f;  // a 16-byte chunk can straddle a neighbour's row
+    }
+    if (live && (seen || !a.accumulate)) {
+        V3 ds = v3(0, 0, 0);
+        V4 dq = {0, 0, 0, 0};
+        if (seen) {
+            cov3d_from_scale_rot_bwd(sc, a.mod, q, dcov6, &ds, &dq);
+            if (a.raw) {
+                dop = act_sigmoid_bwd(opac, dop);
+                ds = act_exp3_bwd(sc, ds);
+                dq = act_normalize4_bwd(q, dn, dq);
+            }
+        }
+        float4* dr = reinterpret_cast<float4*>(a.dL_drotations) + i;
+        float4* dp = reinterpret_cast<float4*>(a.dL_dreps) + i;
+        if (a.accumulate) {
+            a.dL_dsh[3 * i] += ddc[0];
+            a.dL_dsh[3 * i + 1] += ddc[1];
+            a.dL_dsh[3 * i + 2] += ddc[2];
+            a.dL_dopacity[i] += dop;
+            a.dL_dmeans3D[3 * i] += dmean.x;
+            a.dL_dmeans3D[3 * i + 1] += dmean.y;
+            a.dL_dmeans3D[3 * i + 2] += dmean.z;
+            a.dL_dscales[3 * i] += ds.x;
+            a.dL_dscales[3 * i + 1] += ds.y;
+            a.dL_dscales[3 * i + 2] += ds.z;
+            const float4 o = *dr;
+            *dr = make_float4(o.x + dq.x, o.y + dq.y, o.z + dq.z, o.w + dq.w);
+            if (a.DIM == 4) {
+                const float4 r = *dp;
+                *dp = make_float4(r.x + drep[0], r.y + drep[1], r.z + drep[2], r.w + drep[3]);
+            }
+        } else {
+            a.dL_dsh[3 * i] = ddc[0];
+            a.dL_dsh[3 * i + 1] = ddc[1];
+            a.dL_dsh[3 * i + 2] = ddc[2];
+            a.dL_dopacity[i] = dop;
+            a.dL_dmeans3D[3 * i] = dmean.x;
+            a.dL_dmeans3D[3 * i + 1] = dmean.y;
+            a.dL_dmeans3D[3 * i + 2] = dmean.z;
+            a.dL_dscales[3 * i] = ds.x;
+            a.dL_dscales[3 * i + 1] = ds.y;
+            a.dL_dscales[3 * i + 2] = ds.z;
+            *dr = make_float4(dq.x, dq.y, dq.z, dq.w);
+            if (a.DIM == 4) *dp = make_float4(drep[0], drep[1], drep[2], drep[3]);
+        }
+    }
+    wave_lds_sync();
+    float* g = a.dL_dsh_rest + (size_t)wave_g0 * REST_ROW_F;
+    if (a.accumulate) {
+        if (rows) rest_rows_copy<2>(g, lds, rows, nrows, lane);
+    } else {
+        rest_rows_copy<1>(g, lds, ~0ull, nrows, lane);
+    }
+}
+
+// dL/dmeans2D of one view straight from its GradRec (the only per-Gaussian
+// gradient a caller needs per view: the densification statistics read it).
+__global__ void __launch_bounds__(256) means2d_grad_kernel(int P, const GradRec* acc, float* dL_dmeans2D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float2 g = *reinterpret_cast<const float2*>(acc + i);
+    dL_dmeans2D[3 * (size_t)i] = g.x;
+    dL_dmeans2D[3 * (size_t)i + 1] = g.y;
+    dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
+}
+
+hipError_t launch_means2d_grad(int P, const GradRec* acc, float* dL_dmeans2D, hipStream_t st) {
+    hipLaunchKernelGGL(means2d_grad_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, acc, dL_dmeans2D);
+    return hipGetLastError();
+}
+
+hipError_t launch_preprocess_bwd_batch(const GsrScene& s, int nviews, const GsrBackwardView* views,
+                                       const GsrBackwardIO& io, hipStream_t st) {
+    PreBwdBatchArgs b;
+    PreBwdArgs& a = b.a;
+    a = PreBwdArgs();
+    a.P = s.P; a.D = s.D; a.M = s.M; a.DIM = s.DIM;
+    a.mod = s.scale_modifier; a.raw = s.raw_params;
+    a.means3D = s.means3D; a.shs = s.shs; a.shs_rest = s.shs_rest; a.opacities = s.opacities;
+    a.scales = s.scales; a.rotations = s.rotations;
+    a.dL_dopacity = io.dL_dopacity; a.dL_dmeans3D = io.dL_dmeans3D; a.dL_dsh = io.dL_dsh;
+    a.dL_dsh_rest = io.dL_dsh_rest; a.dL_dscales = io.dL_dscales; a.dL_drotations = io.dL_drotations;
+    a.dL_dreps = io.dL_dreps;
+    const dim3 grid((s.P + 255) / 256), block(256);
+    for (int v0 = 0; v0 < nviews; v0 += MAX_BATCH_VIEWS) {
+        b.nviews = nviews - v0 < MAX_BATCH_VIEWS ? nviews - v0 : MAX_BATCH_VIEWS;
+        a.accumulate = (io.accumulate || v0 > 0) ? 1 : 0;
+        for (int k = 0; k < b.nviews; ++k) {
+            const GsrBackwardView& gv = views[v0 + k];
+            BatchView& bv = b.v[k];
+            bv.cam.view = gv.viewmatrix; bv.cam.proj = gv.projmatrix; bv.cam.campos = gv.campos;
+            bv.tanx = gv.tanfovx; bv.tany = gv.tanfovy; bv.W = gv.W; bv.H = gv.H; bv.aa = gv.antialiasing;
+            bv.has_invdepth = gv.has_invdepth;
+            bv.radii = gv.radii;
+            bv.clamped = geom_buf(gv.geom_buffer, (size_t)s.P).clamped;
+            bv.acc = (const GradRec*)gv.work;
+        }
+        hipLaunchKernelGGL(preprocess_bwd_batch_kernel, grid, block, 0, st, b);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_preprocess_bwd(const GsrScene& s, const int* radii, const GeomBuf& g, const GsrBackwardIO& io,
                                  const GradRec* acc, hipStream_t st) {
     PreBwdArgs a;

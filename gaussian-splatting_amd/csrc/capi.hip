@@ -138,24 +138,12 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
     return GSR_OK;
 }
 
-int gsr_backward(const GsrScene* s, const int* radii, const void* geom_buffer, const void* binning_buffer,
-                 const void* image_buffer, int64_t R, const GsrBackwardIO* io, void* stream) {
-    int rc = check_scene(s);
-    if (rc != GSR_OK) return rc;
-    if (!io) return GSR_ERR_ARG;
-    if (s->P == 0) return GSR_OK;
+static int backward_blend(const GsrScene* s, const int* radii, const void* geom_buffer, const void* binning_buffer,
+                          const void* image_buffer, int64_t R, const GsrBackwardIO* io, hipStream_t st) {
     if (!radii || !geom_buffer || !image_buffer || !io->dL_dout_color || !io->work) return GSR_ERR_ARG;
-    if (!io->dL_dmeans2D || !io->dL_dopacity || !io->dL_dmeans3D) return GSR_ERR_ARG;
-    // the two intermediate gradients are only outputs when the matching precomputed input was given
-    if (s->colors_precomp && !io->dL_dcolors) return GSR_ERR_ARG;
-    if (s->cov3D_precomp && !io->dL_dcov3D) return GSR_ERR_ARG;
-    if (s->M > 0 && s->shs && !io->dL_dsh) return GSR_ERR_ARG;
-    if (s->shs_rest && !io->dL_dsh_rest) return GSR_ERR_ARG;
-    if (s->scales && (!io->dL_dscales || !io->dL_drotations)) return GSR_ERR_ARG;
-    if (s->DIM > 0 && (!io->dL_dreps || !io->dL_dout_reps)) return GSR_ERR_ARG;
+    if (s->DIM > 0 && !io->dL_dout_reps) return GSR_ERR_ARG;
     if (io->work_bytes < gsr_backward_work_bytes(s->P)) return GSR_ERR_BUFFER;
     if (R > 0 && !binning_buffer) return GSR_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
     const bool debug = s->debug != 0;
     const GeomBuf g = geom_buf(geom_buffer, (size_t)s->P);
     const ImageView im = image_view((void*)image_buffer, (size_t)s->W, (size_t)s->H);
@@ -169,8 +157,72 @@ int gsr_backward(const GsrScene* s, const int* radii, const void* geom_buffer, c
         GSR_TRY(launch_render_bwd(*s, g, im, b.vals[res], *io, acc, st));
     }
     mark(s, GSR_EV_BWD_RENDER, st);
-    GSR_TRY(launch_preprocess_bwd(*s, radii, g, *io, acc, st));
+    return GSR_OK;
+}
+
+int gsr_backward(const GsrScene* s, const int* radii, const void* geom_buffer, const void* binning_buffer,
+                 const void* image_buffer, int64_t R, const GsrBackwardIO* io, void* stream) {
+    int rc = check_scene(s);
+    if (rc != GSR_OK) return rc;
+    if (!io) return GSR_ERR_ARG;
+    if (s->P == 0) return GSR_OK;
+    if (!io->dL_dmeans2D || !io->dL_dopacity || !io->dL_dmeans3D) return GSR_ERR_ARG;
+    // the two intermediate gradients are only outputs when the matching precomputed input was given
+    if (s->colors_precomp && !io->dL_dcolors) return GSR_ERR_ARG;
+    if (s->cov3D_precomp && !io->dL_dcov3D) return GSR_ERR_ARG;
+    if (s->M > 0 && s->shs && !io->dL_dsh) return GSR_ERR_ARG;
+    if (s->shs_rest && !io->dL_dsh_rest) return GSR_ERR_ARG;
+    if (s->scales && (!io->dL_dscales || !io->dL_drotations)) return GSR_ERR_ARG;
+    if (s->DIM > 0 && !io->dL_dreps) return GSR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool debug = s->debug != 0;
+    rc = backward_blend(s, radii, geom_buffer, binning_buffer, image_buffer, R, io, st);
+    if (rc != GSR_OK) return rc;
+    const GeomBuf g = geom_buf(geom_buffer, (size_t)s->P);
+    GSR_TRY(launch_preprocess_bwd(*s, radii, g, *io, (const GradRec*)io->work, st));
     mark(s, GSR_EV_BWD_PREPROCESS, st);
+    return GSR_OK;
+}
+
+int gsr_backward_blend(const GsrScene* s, const int* radii, const void* geom_buffer, const void* binning_buffer,
+                       const void* image_buffer, int64_t R, const GsrBackwardIO* io, void* stream) {
+    int rc = check_scene(s);
+    if (rc != GSR_OK) return rc;
+    if (!io) return GSR_ERR_ARG;
+    if (s->P == 0) return GSR_OK;
+    if (!io->dL_dmeans2D) return GSR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool debug = s->debug != 0;
+    rc = backward_blend(s, radii, geom_buffer, binning_buffer, image_buffer, R, io, st);
+    if (rc != GSR_OK) return rc;
+    GSR_TRY(launch_means2d_grad(s->P, (const GradRec*)io->work, io->dL_dmeans2D, st));
+    mark(s, GSR_EV_BWD_PREPROCESS, st);
+    return GSR_OK;
+}
+
+int gsr_backward_geometry_batch(const GsrScene* s, int nviews, const GsrBackwardView* views, const GsrBackwardIO* io,
+                                void* stream) {
+    if (!s || !io || nviews < 0 || (nviews > 0 && !views)) return GSR_ERR_ARG;
+    if (s->P < 0) return GSR_ERR_ARG;
+    if (s->DIM != 0 && s->DIM != 4) return GSR_ERR_DIM;
+    if (s->P == 0 || nviews == 0) return GSR_OK;
+    if (!s->means3D || !s->opacities || !s->scales || !s->rotations || !s->shs || !s->shs_rest) return GSR_ERR_ARG;
+    if (s->M != 16 || s->D < 0 || s->D > 3 || s->cov3D_precomp || s->colors_precomp) return GSR_ERR_ARG;
+    if (!io->dL_dopacity || !io->dL_dmeans3D || !io->dL_dsh || !io->dL_dsh_rest || !io->dL_dscales ||
+        !io->dL_drotations)
+        return GSR_ERR_ARG;
+    if (s->DIM > 0 && !io->dL_dreps) return GSR_ERR_ARG;
+    for (int v = 0; v < nviews; ++v) {
+        const GsrBackwardView& gv = views[v];
+        if (!gv.viewmatrix || !gv.projmatrix || !gv.campos || !gv.radii || !gv.geom_buffer || !gv.work ||
+            gv.W <= 0 || gv.H <= 0)
+            return GSR_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const bool debug = s->debug != 0;
+    mark(s, GSR_EV_BATCH_BEGIN, st);
+    GSR_TRY(launch_preprocess_bwd_batch(*s, nviews, views, *io, st));
+    mark(s, GSR_EV_BATCH, st);
     return GSR_OK;
 }
 

@@ -90,6 +90,10 @@ hipError_t launch_render_bwd(const GsrScene& s, const GeomBuf& g, const ImageVie
 hipError_t launch_preprocess_bwd(const GsrScene& s, const int* radii, const GeomBuf& g, const GsrBackwardIO& io,
                                  const GradRec* acc, hipStream_t st);
 
+hipError_t launch_means2d_grad(int P, const GradRec* acc, float* dL_dmeans2D, hipStream_t st);
+hipError_t launch_preprocess_bwd_batch(const GsrScene& s, int nviews, const GsrBackwardView* views,
+                                       const GsrBackwardIO& io, hipStream_t st);
+
 hipError_t launch_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible,
                        int64_t N, int M, const AdamConst& c, hipStream_t st);
 

@@ -7,7 +7,8 @@ import ctypes as C
 
 import torch
 
-from _gsplat_lib import (GsrBackwardIO, GsrForwardOut, GsrScene, check, dev_f32, lib, profile_events, ptr, stream_of)
+from _gsplat_lib import (GsrBackwardIO, GsrBackwardView, GsrForwardOut, GsrScene, check, dev_f32, lib, profile_events,
+                         ptr, stream_of)
 
 SUPPORTED_DIMS = (0, 4)
 
@@ -174,6 +175,81 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
                                  int(R), C.byref(io), stream_of(dev)), "rasterize_gaussians_backward")
     res = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dreps)
     return res + (dL_dsh_rest,) if split else res
+
+
+def rasterize_gaussians_backward_blend(background, means3D, radii, opacities, scales, rotations, scale_modifier,
+                                       viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_invdepth,
+                                       dL_dout_reps, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
+                                       antialiasing, debug, reps, sh_rest, raw_params):
+    """First half of the backward for one view (no counterpart in the reference):
+    the blend backward into a fresh per-Gaussian accumulator buffer.  Returns
+    (dL_dmeans2D, work); `work` goes to backward_geometry_batch later."""
+    L = lib()
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    keep = []
+    with torch.cuda.device(dev):
+        s = _scene(background, means3D, None, opacities, scales, rotations, scale_modifier, None, viewmatrix,
+                   projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, False, antialiasing, debug, reps, keep,
+                   sh_rest=sh_rest, raw=raw_params)
+        f32 = dict(dtype=torch.float32, device=dev)
+        dL_dmeans2D = torch.empty((P, 3), **f32)
+        work = torch.empty((L.gsr_backward_work_bytes(P),), dtype=torch.uint8, device=dev)
+        if P != 0:
+            gc = dev_f32(dL_dout_color, dev, "dL_dout_color")
+            gd = dev_f32(dL_dout_invdepth, dev, "dL_dout_invdepth")
+            gr = dev_f32(dL_dout_reps, dev, "dL_dout_reps") if s.DIM else None
+            if s.DIM and gr is None:
+                gr = torch.zeros((s.DIM, H, W), **f32)
+            io = GsrBackwardIO()
+            io.dL_dout_color, io.dL_dout_invdepth, io.dL_dout_reps = ptr(gc), ptr(gd), ptr(gr)
+            io.dL_dmeans2D = ptr(dL_dmeans2D)
+            io.work, io.work_bytes = ptr(work), work.numel()
+            check(L.gsr_backward_blend(C.byref(s), ptr(radii), ptr(geomBuffer), ptr(binningBuffer), ptr(imageBuffer),
+                                       int(R), C.byref(io), stream_of(dev)), "rasterize_gaussians_backward_blend")
+    return dL_dmeans2D, work
+
+
+def backward_geometry_batch(means3D, opacities, scales, rotations, scale_modifier, sh, sh_rest, degree, reps, raw_params,
+                            views, into, accumulate, debug=False):
+    """Second half of the backward for a batch of views: `views` is a list of
+    dicts (viewmatrix, projmatrix, campos, tanfovx, tanfovy, W, H, antialiasing,
+    has_invdepth, radii, geom, work); the parameter gradients summed over the
+    views are written (or, with `accumulate`, added) into the tensors of `into`
+    (keys means3D, opacity, sh, sh_rest, scales, rotations, reps)."""
+    L = lib()
+    dev = means3D.device
+    P = means3D.size(0)
+    if P == 0 or not views:
+        return
+    keep = []
+    with torch.cuda.device(dev):
+        v0 = views[0]
+        s = _scene(None, means3D, None, opacities, scales, rotations, scale_modifier, None, v0["viewmatrix"],
+                   v0["projmatrix"], v0["tanfovx"], v0["tanfovy"], v0["H"], v0["W"], sh, degree, v0["campos"], False,
+                   False, debug, reps, keep, sh_rest=sh_rest, raw=raw_params)
+        arr = (GsrBackwardView * len(views))()
+        for k, v in enumerate(views):
+            for name in ("viewmatrix", "projmatrix", "campos"):
+                c = dev_f32(v[name], dev, name)
+                keep.append(c)
+                setattr(arr[k], name, ptr(c))
+            arr[k].tanfovx, arr[k].tanfovy = float(v["tanfovx"]), float(v["tanfovy"])
+            arr[k].W, arr[k].H = int(v["W"]), int(v["H"])
+            arr[k].antialiasing, arr[k].has_invdepth = int(bool(v["antialiasing"])), int(bool(v["has_invdepth"]))
+            arr[k].radii, arr[k].geom_buffer, arr[k].work = ptr(v["radii"]), ptr(v["geom"]), ptr(v["work"])
+        io = GsrBackwardIO()
+        for key, field in (("means3D", "dL_dmeans3D"), ("opacity", "dL_dopacity"), ("sh", "dL_dsh"),
+                           ("sh_rest", "dL_dsh_rest"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"),
+                           ("reps", "dL_dreps")):
+            t = into.get(key)
+            if t is not None and (t.dtype != torch.float32 or t.device != dev or not t.is_contiguous()):
+                raise RuntimeError(f"gradient buffer '{key}' must be a contiguous float32 tensor on {dev}")
+            setattr(io, field, ptr(t))
+        io.accumulate = int(bool(accumulate))
+        check(L.gsr_backward_geometry_batch(C.byref(s), len(views), arr, C.byref(io), stream_of(dev)),
+              "backward_geometry_batch")
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

@@ -96,18 +96,41 @@ class ParamGradSink:
     backward of every optimiser step instead of zeroing the gradients."""
 
     NAMES = ("means3D", "sh", "sh_rest", "opacity", "scales", "rotations", "reps")
+    MAX_PENDING = 8
 
-    def __init__(self, xyz, features_dc, features_rest, opacity, scaling, rotation, reps=None):
+    def __init__(self, xyz, features_dc, features_rest, opacity, scaling, rotation, reps=None, defer=False):
+        """defer: a view's backward only runs the blend backward (and returns the
+        screen-space gradient); the per-Gaussian backward of all the views of a
+        step runs once, in `flush()`, reading every parameter and writing every
+        gradient a single time.  Call `flush()` before using the gradients."""
         self.params = dict(means3D=xyz, sh=features_dc, sh_rest=features_rest, opacity=opacity, scales=scaling,
                            rotations=rotation, reps=reps)
         self.grads = {k: torch.zeros_like(p) for k, p in self.params.items() if p is not None and p.numel() != 0}
         for k, g in self.grads.items():
             self.params[k].grad = g
         self.fresh = True
+        self.defer = bool(defer) and "sh_rest" in self.grads and \
+            features_dc.size(1) + features_rest.size(1) == 16
+        self.pending = []
+        self.pending_cfg = None
 
     def begin_step(self):
         """The next backward overwrites the buffers, the ones after it accumulate."""
+        self.pending = []
         self.fresh = True
+
+    def flush(self):
+        """Run the per-Gaussian backward of the views whose backward was deferred."""
+        if not self.pending:
+            return
+        scale_modifier, degree, debug = self.pending_cfg
+        p = self.params
+        empty = torch.Tensor([])
+        _C.backward_geometry_batch(p["means3D"], p["opacity"], p["scales"], p["rotations"], scale_modifier, p["sh"],
+                                   p["sh_rest"], degree, empty if p["reps"] is None else p["reps"], True, self.pending,
+                                   self.grads, not self.fresh, debug)
+        self.pending = []
+        self.fresh = False
 
     def tensors(self):
         return list(self.grads.values())
@@ -143,6 +166,22 @@ class _RasterizeGaussiansParams(torch.autograd.Function):
          reps) = ctx.saved_tensors
         sink = ctx.sink
         empty = torch.Tensor([])
+        if sink is not None and sink.defer:
+            cfg = (rs.scale_modifier, rs.sh_degree, rs.debug)
+            if sink.pending and (sink.pending_cfg != cfg or len(sink.pending) >= sink.MAX_PENDING):
+                sink.flush()
+            g_means2D, work = _C.rasterize_gaussians_backward_blend(
+                rs.bg, xyz, radii, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix, rs.projmatrix,
+                rs.tanfovx, rs.tanfovy, grad_out_color, grad_out_depth, grad_out_reps, features_dc, rs.sh_degree,
+                rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.antialiasing, rs.debug, reps,
+                features_rest, True)
+            sink.pending_cfg = cfg
+            sink.pending.append(dict(
+                viewmatrix=rs.viewmatrix, projmatrix=rs.projmatrix, campos=rs.campos, tanfovx=rs.tanfovx,
+                tanfovy=rs.tanfovy, W=rs.image_width, H=rs.image_height, antialiasing=rs.antialiasing,
+                has_invdepth=grad_out_depth is not None and grad_out_depth.numel() != 0, radii=radii,
+                geom=geomBuffer, work=work))
+            return (None, g_means2D, None, None, None, None, None, None, None, None)
         into, accumulate = None, False
         if sink is not None:
             into, accumulate = sink.grads, not sink.fresh

@@ -103,8 +103,10 @@ typedef enum {
     GSR_EV_BWD_BEGIN = 10,
     GSR_EV_BWD_CLEAR = 11,     /* gradient accumulator clear */
     GSR_EV_BWD_RENDER = 12,    /* backward blend */
-    GSR_EV_BWD_PREPROCESS = 13,/* per-Gaussian backward */
-    GSR_NUM_PROFILE_EVENTS = 14
+    GSR_EV_BWD_PREPROCESS = 13,/* per-Gaussian backward (gsr_backward) or screen-space gradient copy (gsr_backward_blend) */
+    GSR_EV_BATCH_BEGIN = 14,
+    GSR_EV_BATCH = 15,         /* per-Gaussian backward of a batch of views (gsr_backward_geometry_batch) */
+    GSR_NUM_PROFILE_EVENTS = 16
 } GsrProfileEvent;
 
 /* Outputs of the forward pass.  None of them needs initialising by the caller. */
@@ -164,6 +166,33 @@ int gsr_forward_stage2(const GsrScene* scene, const GsrForwardOut* out, int64_t 
 
 int gsr_backward(const GsrScene* scene, const int* radii, const void* geom_buffer, const void* binning_buffer,
                  const void* image_buffer, int64_t num_rendered, const GsrBackwardIO* io, void* stream);
+
+/* Deferred backward for a batch of views (no counterpart in the reference, which backpropagates one
+ * view at a time; for callers that accumulate the gradients of several views before an optimiser
+ * step).  gsr_backward_blend is the first half of gsr_backward: the blend backward of one view into
+ * io->work (its per-Gaussian accumulators) and io->dL_dmeans2D; only io->dL_dout_*, io->work and
+ * io->dL_dmeans2D are used.  gsr_backward_geometry_batch is the second half for all the views
+ * together: each Gaussian's parameters are read once and every parameter gradient (dL_dmeans3D,
+ * dL_dopacity, dL_dsh + dL_dsh_rest, dL_dscales, dL_drotations, dL_dreps) is written or, with
+ * io->accumulate, added to once, the sum over the views.  It needs the SH tensors split
+ * (scene->shs_rest), M == 16 and scales + rotations; the camera fields of `scene` are ignored. */
+typedef struct {
+    const float* viewmatrix;   /* device [16] */
+    const float* projmatrix;   /* device [16] */
+    const float* campos;       /* device [3] */
+    float tanfovx, tanfovy;
+    int W, H;
+    int antialiasing;
+    int has_invdepth;          /* that view's backward was given dL_dout_invdepth */
+    const int* radii;          /* device [P], from that view's forward */
+    const void* geom_buffer;   /* that view's geometry buffer */
+    const void* work;          /* that view's accumulators, filled by gsr_backward_blend */
+} GsrBackwardView;
+
+int gsr_backward_blend(const GsrScene* scene, const int* radii, const void* geom_buffer, const void* binning_buffer,
+                       const void* image_buffer, int64_t num_rendered, const GsrBackwardIO* io, void* stream);
+int gsr_backward_geometry_batch(const GsrScene* scene, int nviews, const GsrBackwardView* views,
+                                const GsrBackwardIO* io, void* stream);
 
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
                      void* stream);

@@ -213,3 +213,74 @@ def test_forward_params_matches_reference_formulation(use_sink):
         assert B[n].grad is not None, n
         assert rel_err(B[n].grad.cpu().numpy(), A[n].grad.cpu().numpy()) <= REL_TOL, n
     assert rel_err(m2b.grad.cpu().numpy(), m2a.grad.cpu().numpy()) <= REL_TOL
+
+
+@pytest.mark.parametrize("nviews", [1, 3, 10])
+def test_deferred_batch_backward_matches_per_view_backward(oracle, nviews):
+    """ParamGradSink(defer=True): blend backward per view, one per-Gaussian backward for the batch.
+    Compared with the per-view accumulate path and, for the sum, with the CPU checker."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, ParamGradSink
+    sc = synth.tiny_scene(P=500, width=96, height=64, seed=23)
+    raw = _raw_scene(sc, seed=4)
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda:0")
+    names = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation", "reps")
+    vals = (sc["means3D"], raw["features_dc"], raw["features_rest"], raw["opacity"], raw["scaling"], raw["rotation"],
+            sc["reps"])
+    A = {n: t(v).requires_grad_(True) for n, v in zip(names, vals)}
+    B = {n: t(v).requires_grad_(True) for n, v in zip(names, vals)}
+    sink_a = ParamGradSink(*[A[n] for n in names])
+    sink_b = ParamGradSink(*[B[n] for n in names], defer=True)
+    assert sink_b.defer
+    cams, settings = [], []
+    for v in range(nviews):
+        ang = 0.25 * (v - nviews / 2)
+        cam = synth.make_camera(96, 64, 0.9, (0.1 + 2.5 * np.sin(ang), -0.05 + 0.1 * v, -2.5 * np.cos(ang)), (0.0, 0.0, 1.0))
+        cams.append(cam)
+        settings.append(GaussianRasterizationSettings(
+            image_height=64, image_width=96, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=t((0.1, 0.2, 0.3)),
+            scale_modifier=1.0, viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=3,
+            campos=t(cam["campos"]), prefiltered=False, debug=True, antialiasing=True))
+    rng = np.random.default_rng(9)
+    ws = [[rng.standard_normal(s).astype(np.float32) for s in ((3, 64, 96), (1, 64, 96), (4, 64, 96))]
+          for _ in range(nviews)]
+
+    def run(P_, sink, step_scale):
+        sink.begin_step()
+        m2s = []
+        for v in range(nviews):
+            m2 = torch.zeros_like(P_["xyz"], requires_grad=True)
+            o = GaussianRasterizer(settings[v]).forward_params(
+                P_["xyz"], m2, P_["features_dc"], P_["features_rest"], P_["opacity"], P_["scaling"], P_["rotation"],
+                P_["reps"], grad_sink=sink)
+            w = ws[v]
+            ((o[0] * t(w[0])).sum() + (o[2] * t(w[1])).sum() + (o[5] * t(w[2])).sum()).mul(step_scale).backward()
+            m2s.append(m2.grad.clone())
+        sink.flush() if sink.defer else None
+        return m2s
+
+    for step_scale in (1.0, -0.5):      # two steps: the second must overwrite, not add to, the first
+        ma = run(A, sink_a, step_scale)
+        mb = run(B, sink_b, step_scale)
+        for n in names:
+            ga, gb = A[n].grad.cpu().numpy(), B[n].grad.cpu().numpy()
+            assert np.isfinite(gb).all(), n
+            assert rel_err(gb, ga) <= REL_TOL, (n, rel_err(gb, ga))
+        for x, y in zip(ma, mb):
+            assert rel_err(y.cpu().numpy(), x.cpu().numpy()) <= REL_TOL
+    # the sum over views against the CPU checker (last step: scale -0.5)
+    o_, s_, r_ = oracle.activate(raw["opacity"], raw["scaling"], raw["rotation"])
+    tot = None
+    for v in range(nviews):
+        sc2 = dict(sc)
+        sc2["opacities"], sc2["scales"], sc2["rotations"], sc2["camera"] = o_, s_, r_, cams[v]
+        f = oracle.forward_from_scene(sc2, bg=(0.1, 0.2, 0.3), antialiasing=True)
+        g = f.backward(*[(-0.5 * w).astype(np.float32) for w in ws[v]])
+        g_op, g_sc, g_rot = oracle.activate_bwd(raw["opacity"], raw["scaling"], raw["rotation"], g["dL_dopacity"],
+                                                g["dL_dscale"], g["dL_drot"])
+        cur = dict(xyz=g["dL_dmean3D"], sh=g["dL_dsh"].reshape(500, 16, 3), opacity=g_op, scaling=g_sc, rotation=g_rot,
+                   reps=g["dL_dreps"])
+        tot = cur if tot is None else {k: tot[k] + cur[k] for k in cur}
+    got_sh = np.concatenate([B["features_dc"].grad.cpu().numpy(), B["features_rest"].grad.cpu().numpy()], axis=1)
+    assert rel_err(got_sh, tot["sh"]) <= REL_TOL
+    for n in ("xyz", "opacity", "scaling", "rotation", "reps"):
+        assert rel_err(B[n].grad.cpu().numpy().reshape(tot[n].shape), tot[n]) <= REL_TOL, n
