@@ -41,7 +41,7 @@ class GsrBackwardIO(C.Structure):
 class GsrBackwardView(C.Structure):
     _fields_ = [("viewmatrix", _vp), ("projmatrix", _vp), ("campos", _vp), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
                 ("W", C.c_int), ("H", C.c_int), ("antialiasing", C.c_int), ("has_invdepth", C.c_int), ("radii", _vp),
-                ("geom_buffer", _vp), ("work", _vp)]
+                ("geom_buffer", _vp), ("work", _vp), ("dL_dmeans2D", _vp)]
 
 
 class GsrLayout(C.Structure):

@@ -360,6 +360,7 @@ struct BatchView {
     const int* radii;
     const uint8_t* clamped;
     const GradRec* acc;
+    float* dL_dmeans2D;  // [P,3] of this view, or null
 };
 
 struct PreBwdBatchArgs {
@@ -386,8 +387,15 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
     float* row = lds + lane * REST_ROW_F;
 
     uint32_t seen = 0;  // bit v: rendered in view v
-    for (int v = 0; v < b.nviews; ++v)
-        if (live && b.v[v].radii[i] > 0) seen |= 1u << v;
+    for (int v = 0; v < b.nviews; ++v) {
+        if (!live) break;
+        if (b.v[v].radii[i] > 0) {
+            seen |= 1u << v;
+        } else if (b.v[v].dL_dmeans2D) {  // the screen-space gradient of a view is per view: zero here
+            float* m2 = b.v[v].dL_dmeans2D + 3 * i;
+            m2[0] = m2[1] = m2[2] = 0.f;
+        }
+    }
     const uint64_t rows = __ballot(seen != 0);
     if (rows == 0 && a.accumulate) return;
     if (rows) rest_rows_copy<0>(const_cast<float*>(a.shs_rest) + (size_t)wave_g0 * REST_ROW_F, lds, rows, nrows, lane);
@@ -465,6 +473,12 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
             dmean = add(dmean, cov2d_bwd(c, mean, cov6, opac, v3(g0.z, g0.w, g1.x), &dop_v,
                                          bv.has_invdepth ? &dinv : nullptr, dcov_v));
             dmean = add(dmean, mean2d_bwd(mean, c.proj, g0.x, g0.y));
+            if (bv.dL_dmeans2D) {
+                float* m2 = bv.dL_dmeans2D + 3 * i;
+                m2[0] = g0.x;
+                m2[1] = g0.y;
+                m2[2] = 0.f;
+            }
             dop += dop_v;
 #pragma unroll
             for (int k = 0; k < 6; ++k) dcov6[k] += dcov_v[k];
@@ -572,6 +586,7 @@ hipError_t launch_preprocess_bwd_batch(const GsrScene& s, int nviews, const GsrB
             bv.radii = gv.radii;
             bv.clamped = geom_buf(gv.geom_buffer, (size_t)s.P).clamped;
             bv.acc = (const GradRec*)gv.work;
+            bv.dL_dmeans2D = gv.dL_dmeans2D;
         }
         hipLaunchKernelGGL(preprocess_bwd_batch_kernel, grid, block, 0, st, b);
     }

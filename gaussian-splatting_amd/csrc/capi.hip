@@ -190,12 +190,11 @@ int gsr_backward_blend(const GsrScene* s, const int* radii, const void* geom_buf
     if (rc != GSR_OK) return rc;
     if (!io) return GSR_ERR_ARG;
     if (s->P == 0) return GSR_OK;
-    if (!io->dL_dmeans2D) return GSR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool debug = s->debug != 0;
     rc = backward_blend(s, radii, geom_buffer, binning_buffer, image_buffer, R, io, st);
     if (rc != GSR_OK) return rc;
-    GSR_TRY(launch_means2d_grad(s->P, (const GradRec*)io->work, io->dL_dmeans2D, st));
+    if (io->dL_dmeans2D) GSR_TRY(launch_means2d_grad(s->P, (const GradRec*)io->work, io->dL_dmeans2D, st));
     mark(s, GSR_EV_BWD_PREPROCESS, st);
     return GSR_OK;
 }

@@ -180,10 +180,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
 def rasterize_gaussians_backward_blend(background, means3D, radii, opacities, scales, rotations, scale_modifier,
                                        viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_invdepth,
                                        dL_dout_reps, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
-                                       antialiasing, debug, reps, sh_rest, raw_params):
+                                       antialiasing, debug, reps, sh_rest, raw_params, want_means2D=True):
     """First half of the backward for one view (no counterpart in the reference):
     the blend backward into a fresh per-Gaussian accumulator buffer.  Returns
-    (dL_dmeans2D, work); `work` goes to backward_geometry_batch later."""
+    (dL_dmeans2D, work); `work` goes to backward_geometry_batch later, which
+    can also fill dL_dmeans2D (want_means2D=False leaves it uninitialised here)."""
     L = lib()
     dev = means3D.device
     P = means3D.size(0)
@@ -204,7 +205,7 @@ def rasterize_gaussians_backward_blend(background, means3D, radii, opacities, sc
                 gr = torch.zeros((s.DIM, H, W), **f32)
             io = GsrBackwardIO()
             io.dL_dout_color, io.dL_dout_invdepth, io.dL_dout_reps = ptr(gc), ptr(gd), ptr(gr)
-            io.dL_dmeans2D = ptr(dL_dmeans2D)
+            io.dL_dmeans2D = ptr(dL_dmeans2D) if want_means2D else None
             io.work, io.work_bytes = ptr(work), work.numel()
             check(L.gsr_backward_blend(C.byref(s), ptr(radii), ptr(geomBuffer), ptr(binningBuffer), ptr(imageBuffer),
                                        int(R), C.byref(io), stream_of(dev)), "rasterize_gaussians_backward_blend")
@@ -215,7 +216,8 @@ def backward_geometry_batch(means3D, opacities, scales, rotations, scale_modifie
                             views, into, accumulate, debug=False):
     """Second half of the backward for a batch of views: `views` is a list of
     dicts (viewmatrix, projmatrix, campos, tanfovx, tanfovy, W, H, antialiasing,
-    has_invdepth, radii, geom, work); the parameter gradients summed over the
+    has_invdepth, radii, geom, work and optionally dL_dmeans2D, a [P,3] tensor
+    that receives that view's screen-space gradient); the parameter gradients summed over the
     views are written (or, with `accumulate`, added) into the tensors of `into`
     (keys means3D, opacity, sh, sh_rest, scales, rotations, reps)."""
     L = lib()
@@ -239,6 +241,7 @@ def backward_geometry_batch(means3D, opacities, scales, rotations, scale_modifie
             arr[k].W, arr[k].H = int(v["W"]), int(v["H"])
             arr[k].antialiasing, arr[k].has_invdepth = int(bool(v["antialiasing"])), int(bool(v["has_invdepth"]))
             arr[k].radii, arr[k].geom_buffer, arr[k].work = ptr(v["radii"]), ptr(v["geom"]), ptr(v["work"])
+            arr[k].dL_dmeans2D = ptr(v.get("dL_dmeans2D"))
         io = GsrBackwardIO()
         for key, field in (("means3D", "dL_dmeans3D"), ("opacity", "dL_dopacity"), ("sh", "dL_dsh"),
                            ("sh_rest", "dL_dsh_rest"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"),

@@ -102,7 +102,9 @@ class ParamGradSink:
         """defer: a view's backward only runs the blend backward (and returns the
         screen-space gradient); the per-Gaussian backward of all the views of a
         step runs once, in `flush()`, reading every parameter and writing every
-        gradient a single time.  Call `flush()` before using the gradients."""
+        gradient a single time.  Call `flush()` before using the gradients: the
+        parameters' and also the `means2D.grad` of the deferred views, which
+        `flush()` fills."""
         self.params = dict(means3D=xyz, sh=features_dc, sh_rest=features_rest, opacity=opacity, scales=scaling,
                            rotations=rotation, reps=reps)
         self.grads = {k: torch.zeros_like(p) for k, p in self.params.items() if p is not None and p.numel() != 0}
@@ -129,6 +131,9 @@ class ParamGradSink:
         _C.backward_geometry_batch(p["means3D"], p["opacity"], p["scales"], p["rotations"], scale_modifier, p["sh"],
                                    p["sh_rest"], degree, empty if p["reps"] is None else p["reps"], True, self.pending,
                                    self.grads, not self.fresh, debug)
+        for v in self.pending:   # the screen-space gradients the batch kernel wrote, one tensor per view
+            m2 = v["means2D"]
+            m2.grad = v["dL_dmeans2D"] if m2.grad is None else m2.grad + v["dL_dmeans2D"]
         self.pending = []
         self.fresh = False
 
@@ -155,6 +160,7 @@ class _RasterizeGaussiansParams(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.sink = sink
+        ctx.means2D = means2D
         ctx.save_for_backward(xyz, scaling, rotation, radii, features_dc, features_rest, opacity, geomBuffer,
                               binningBuffer, imgBuffer, reps)
         return color, radii, invdepths, gauss_sum, gauss_count, out_reps
@@ -174,14 +180,14 @@ class _RasterizeGaussiansParams(torch.autograd.Function):
                 rs.bg, xyz, radii, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix, rs.projmatrix,
                 rs.tanfovx, rs.tanfovy, grad_out_color, grad_out_depth, grad_out_reps, features_dc, rs.sh_degree,
                 rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.antialiasing, rs.debug, reps,
-                features_rest, True)
+                features_rest, True, want_means2D=False)
             sink.pending_cfg = cfg
             sink.pending.append(dict(
                 viewmatrix=rs.viewmatrix, projmatrix=rs.projmatrix, campos=rs.campos, tanfovx=rs.tanfovx,
                 tanfovy=rs.tanfovy, W=rs.image_width, H=rs.image_height, antialiasing=rs.antialiasing,
                 has_invdepth=grad_out_depth is not None and grad_out_depth.numel() != 0, radii=radii,
-                geom=geomBuffer, work=work))
-            return (None, g_means2D, None, None, None, None, None, None, None, None)
+                geom=geomBuffer, work=work, dL_dmeans2D=g_means2D, means2D=ctx.means2D))
+            return (None,) * 10
         into, accumulate = None, False
         if sink is not None:
             into, accumulate = sink.grads, not sink.fresh

@@ -170,8 +170,8 @@ int gsr_backward(const GsrScene* scene, const int* radii, const void* geom_buffe
 /* Deferred backward for a batch of views (no counterpart in the reference, which backpropagates one
  * view at a time; for callers that accumulate the gradients of several views before an optimiser
  * step).  gsr_backward_blend is the first half of gsr_backward: the blend backward of one view into
- * io->work (its per-Gaussian accumulators) and io->dL_dmeans2D; only io->dL_dout_*, io->work and
- * io->dL_dmeans2D are used.  gsr_backward_geometry_batch is the second half for all the views
+ * io->work (its per-Gaussian accumulators) and, if not NULL, io->dL_dmeans2D; only io->dL_dout_*,
+ * io->work and io->dL_dmeans2D are used.  gsr_backward_geometry_batch is the second half for all the views
  * together: each Gaussian's parameters are read once and every parameter gradient (dL_dmeans3D,
  * dL_dopacity, dL_dsh + dL_dsh_rest, dL_dscales, dL_drotations, dL_dreps) is written or, with
  * io->accumulate, added to once, the sum over the views.  It needs the SH tensors split
@@ -187,6 +187,8 @@ typedef struct {
     const int* radii;          /* device [P], from that view's forward */
     const void* geom_buffer;   /* that view's geometry buffer */
     const void* work;          /* that view's accumulators, filled by gsr_backward_blend */
+    float* dL_dmeans2D;        /* device [P,3] or NULL: that view's screen-space gradient, written by the batch call
+                                  (then gsr_backward_blend can be given io->dL_dmeans2D = NULL and skips its copy) */
 } GsrBackwardView;
 
 int gsr_backward_blend(const GsrScene* scene, const int* radii, const void* geom_buffer, const void* binning_buffer,

@@ -254,9 +254,9 @@ def test_deferred_batch_backward_matches_per_view_backward(oracle, nviews):
                 P_["reps"], grad_sink=sink)
             w = ws[v]
             ((o[0] * t(w[0])).sum() + (o[2] * t(w[1])).sum() + (o[5] * t(w[2])).sum()).mul(step_scale).backward()
-            m2s.append(m2.grad.clone())
-        sink.flush() if sink.defer else None
-        return m2s
+            m2s.append(m2)
+        sink.flush() if sink.defer else None      # also fills the means2D.grad of the deferred views
+        return [m.grad.clone() for m in m2s]
 
     for step_scale in (1.0, -0.5):      # two steps: the second must overwrite, not add to, the first
         ma = run(A, sink_a, step_scale)
