@@ -19,7 +19,8 @@ KERNEL_KEYS = {  # kernel symbol substring -> bench.py kernel name
     "preprocess_fwd_kernel": "preprocess", "depth_keys_kernel": "depth_order:keys", "order_sums_kernel": "depth_order:sums",
     "emit_keys_kernel": "emit_keys", "onesweep_kernel": "sort:onesweep", "sort_hist_kernel": "sort:hist",
     "sort_scan_hist_kernel": "sort:scan", "tile_ranges_kernel": "tile_ranges", "render_fwd_kernel": "render_fwd",
-    "render_bwd_kernel": "render_bwd", "preprocess_bwd_kernel": "preprocess_bwd", "ssim_fwd": "ssim_fwd",
+    "render_bwd_kernel": "render_bwd", "preprocess_bwd_kernel": "preprocess_bwd",
+    "preprocess_bwd_batch_kernel": "preprocess_bwd_batch", "order_gather_kernel": "depth_order:gather", "ssim_fwd": "ssim_fwd",
     "ssim_bwd": "ssim_bwd", "scan_blocks_kernel": "scan", "finish_gstat_kernel": "finish_stats"}
 
 
