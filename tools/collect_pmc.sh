@@ -7,7 +7,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc
 rm -rf "$OUT"; mkdir -p "$OUT"   # (delete the local gpurun_out/pmc too before collecting: results are merged into it)
-BENCH="bench.py --steps 2 --warmup 1 --views-per-gpu 2 --no-extras --no-cpu-baseline $*"
+BENCH="bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline $*"
 run_pass() {
     name=$1; shift
     echo "== pass $name: $*"
