@@ -321,11 +321,12 @@ def main():
     passes = ((gx * gy).bit_length() + 7) // 8   # the instance sort only orders the tile bits
 
     # workload counters of this rank's views (outside the timed region)
-    vis_l, R_l = [], []
+    vis_l, R_l, pairs_l = [], [], []
     with torch.no_grad():
         for rs, _ in views:
             o = render_params(params, rs)
             vis_l.append(int((o[1] > 0).sum().item()))
+            pairs_l.append(int(o[4].sum(dtype=torch.int64).item()))   # (pixel, Gaussian) pairs the forward blend tested
         from diff_gaussian_rasterization import _C as RC
         e = torch.Tensor([])
         for rs, _ in views:
@@ -333,7 +334,7 @@ def main():
                 rs.bg, params["xyz"], e, params["opacity"], params["scaling"], params["rotation"], 1.0, e,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, params["features_dc"], rs.sh_degree,
                 rs.campos, False, True, False, params["reps"], sh_rest=params["features_rest"], raw_params=True)[0]))
-    visible, R = float(np.mean(vis_l)), float(np.mean(R_l))
+    visible, R, pairs = float(np.mean(vis_l)), float(np.mean(R_l)), float(np.mean(pairs_l))
 
     extras = {}
     if rank == 0 and world == 1 and not args.fwd_only and not args.no_extras:
@@ -427,6 +428,7 @@ def main():
                                     "gradient all-reduce when n_gpus > 1; no optimizer"),
                        "api": "forward_params (raw parameters)" if use_params else "reference signature",
                        "gaussians": P, "views_per_gpu_per_step": V, "visible_mean": visible, "num_rendered_mean": R,
+                       "pairs_tested_mean": pairs, "tile_list_mean": R / (gx * gy),
                        "image": [W, H], "parallelism": f"view-sharded x{world}, full replicas" if world > 1 else "single GPU",
                        "collective_backend": (backend if world > 1 else None)},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
