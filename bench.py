@@ -389,6 +389,23 @@ def main():
             extras.setdefault("optimizer_step_ms", {})[name] = 1e3 / timed(lambda: fn(opt), 10)
             del opt
 
+        # densification statistics after a view: the fused kernel next to the reference's formulation
+        from gsplat_optim import add_densification_stats
+        o = render_params(params, rs0)
+        radii0 = o[1]
+        g2 = torch.randn((P, 3), device=dev)
+        acc, den, mx = torch.zeros((P, 1), device=dev), torch.zeros((P, 1), device=dev), torch.zeros((P,), device=dev)
+
+        def stats_reference():
+            vf = (radii0 > 0).nonzero()
+            mx[vf] = torch.max(mx[vf], radii0[vf].float())
+            acc[vf] += torch.norm(g2[vf, :2], dim=-1, keepdim=True)
+            den[vf] += 1
+
+        extras["densify_stats_ms"] = {
+            "fused": 1e3 / timed(lambda: add_densification_stats(radii0, g2, acc, den, mx), 10),
+            "torch_reference_formulation": 1e3 / timed(stats_reference, 10)}
+
     if rank == 0:
         traffic = load_pmc_traffic(P, W, H)
         per_kernel = {}

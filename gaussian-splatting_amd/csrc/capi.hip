@@ -327,6 +327,15 @@ int gso_adam_update(float* param, const float* grad, float* exp_avg, float* exp_
                                   (hipStream_t)stream));
 }
 
+int gso_densify_stats(int P, const int* radii, const float* dL_dmeans2D, float* xyz_gradient_accum, float* denom,
+                      float* max_radii2D, void* stream) {
+    if (P < 0) return GSR_ERR_ARG;
+    if (P == 0) return GSR_OK;
+    if (!radii || !dL_dmeans2D || !xyz_gradient_accum || !denom || !max_radii2D) return GSR_ERR_ARG;
+    return hip_status(launch_densify_stats(P, radii, dL_dmeans2D, xyz_gradient_accum, denom, max_radii2D,
+                                           (hipStream_t)stream));
+}
+
 const char* gsr_status_string(int status) {
     switch (status) {
         case GSR_OK: return "ok";

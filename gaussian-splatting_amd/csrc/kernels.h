@@ -97,6 +97,9 @@ hipError_t launch_preprocess_bwd_batch(const GsrScene& s, int nviews, const GsrB
 hipError_t launch_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible,
                        int64_t N, int M, const AdamConst& c, hipStream_t st);
 
+hipError_t launch_densify_stats(int P, const int* radii, const float* dL_dmeans2D, float* xyz_gradient_accum,
+                                float* denom, float* max_radii2D, hipStream_t st);
+
 hipError_t launch_knn(int P, const float* points, float* out, void* temp, hipStream_t st);
 size_t knn_temp_bytes(int P);
 

@@ -59,4 +59,33 @@ hipError_t launch_adam(float* param, const float* grad, float* exp_avg, float* e
     return hipGetLastError();
 }
 
+// Densification statistics of one rendered view in one pass over the Gaussians
+// (train.py:298-312 and scene/gaussian_model.py:202-214 do it with a nonzero()
+// of the visibility mask, which blocks the host, and five indexed updates):
+// for every Gaussian with radii > 0
+//   max_radii2D       = max(max_radii2D, radii)
+//   xyz_gradient_accum += |dL/dmeans2D.xy|
+//   denom             += 1
+__global__ void __launch_bounds__(256) densify_stats_kernel(int P, const int* __restrict__ radii,
+                                                            const float* __restrict__ dL_dmeans2D,
+                                                            float* __restrict__ xyz_gradient_accum,
+                                                            float* __restrict__ denom, float* __restrict__ max_radii2D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (!(r > 0)) return;
+    const float gx = dL_dmeans2D[3 * (size_t)i], gy = dL_dmeans2D[3 * (size_t)i + 1];
+    max_radii2D[i] = fmax_(max_radii2D[i], (float)r);
+    xyz_gradient_accum[i] += sqrtf(gx * gx + gy * gy);
+    denom[i] += 1.0f;
+}
+
+hipError_t launch_densify_stats(int P, const int* radii, const float* dL_dmeans2D, float* xyz_gradient_accum,
+                                float* denom, float* max_radii2D, hipStream_t st) {
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, radii, dL_dmeans2D,
+                       xyz_gradient_accum, denom, max_radii2D);
+    return hipGetLastError();
+}
+
 }  // namespace gs

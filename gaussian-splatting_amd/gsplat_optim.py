@@ -73,3 +73,22 @@ class FusedGaussianAdam(torch.optim.Adam):
                                             rows, width, lr, beta1, beta2, eps, bc1, bc2s, stream_of(p.device)),
                           "adam update")
         return loss
+
+
+@torch.no_grad()
+def add_densification_stats(radii, viewspace_grad, xyz_gradient_accum, denom, max_radii2D):
+    """One fused pass for what train.py:298-312 and GaussianModel.add_densification_stats
+    (scene/gaussian_model.py:202-214) do after every iteration, without the host-blocking
+    `nonzero()` of the visibility mask: for Gaussians with radii > 0,
+    max_radii2D = max(max_radii2D, radii), xyz_gradient_accum += |viewspace_grad[:, :2]|, denom += 1.
+    All tensors are updated in place; `viewspace_grad` is `viewspace_point_tensor.grad` ([P,3])."""
+    P = radii.shape[0]
+    for t, shape in ((viewspace_grad, (P, 3)), (xyz_gradient_accum, (P, 1)), (denom, (P, 1)), (max_radii2D, (P,))):
+        if tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError(f"expected a contiguous float32 GPU tensor of shape {shape}, got {tuple(t.shape)} {t.dtype}")
+    if radii.dtype != torch.int32 or not radii.is_contiguous():
+        raise RuntimeError("radii must be the contiguous int32 tensor the rasterizer returned")
+    with torch.cuda.device(radii.device):
+        check(lib().gso_densify_stats(P, radii.data_ptr(), viewspace_grad.data_ptr(), xyz_gradient_accum.data_ptr(),
+                                      denom.data_ptr(), max_radii2D.data_ptr(), stream_of(radii.device)),
+              "densify stats")

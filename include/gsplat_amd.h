@@ -247,6 +247,13 @@ int gso_adam_update(float* param, const float* grad, float* exp_avg, float* exp_
                     int64_t N, int M, double lr, double beta1, double beta2, double eps, double bias_correction1,
                     double bias_correction2_sqrt, void* stream);
 
+/* Densification statistics after one view, in place (all device pointers): for every Gaussian with
+ * radii > 0, max_radii2D = max(max_radii2D, radii) (train.py:298-309), xyz_gradient_accum +=
+ * |dL_dmeans2D.xy| and denom += 1 (scene/gaussian_model.py:202-214).  radii [P] int, dL_dmeans2D [P,3],
+ * xyz_gradient_accum [P,1], denom [P,1], max_radii2D [P]. */
+int gso_densify_stats(int P, const int* radii, const float* dL_dmeans2D, float* xyz_gradient_accum, float* denom,
+                      float* max_radii2D, void* stream);
+
 const char* gsr_status_string(int status);
 
 #ifdef __cplusplus

@@ -297,6 +297,18 @@ def adam_update(param, grad, exp_avg, exp_avg_sq, visible, lr, beta1, beta2, eps
     return p, m, v
 
 
+def densify_stats(radii, viewspace_grad, xyz_gradient_accum, denom, max_radii2D):
+    """train.py:298-312 and scene/gaussian_model.py:202-214 restated in numpy (float32):
+    returns the updated (xyz_gradient_accum, denom, max_radii2D)."""
+    vis = np.nonzero(np.asarray(radii) > 0)[0]
+    acc, den, mx = (np.array(a, np.float32, copy=True) for a in (xyz_gradient_accum, denom, max_radii2D))
+    mx[vis] = np.maximum(mx[vis], np.asarray(radii)[vis].astype(np.float32))
+    g = np.asarray(viewspace_grad, np.float32)[vis, :2]
+    acc[vis] += np.sqrt(g[:, 0] * g[:, 0] + g[:, 1] * g[:, 1], dtype=np.float32).reshape(-1, 1)
+    den[vis] += np.float32(1)
+    return acc, den, mx
+
+
 def sh_eval(deg, pos, campos, shs):
     pos, campos, shs = _c(pos), _c(campos), _c(shs)
     N, M = shs.shape[0], shs.shape[1]

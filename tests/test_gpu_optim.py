@@ -100,3 +100,28 @@ def test_optimizer_class_against_torch_adam():
         p, b = grp["params"][0].detach(), before[grp["name"]]
         assert torch.equal(p[~vis], b[~vis])
         assert not torch.equal(p[vis], b[vis])
+
+
+def test_densify_stats(oracle):
+    from gsplat_optim import add_densification_stats
+    rng = np.random.default_rng(11)
+    P = 100_003
+    radii = (rng.integers(0, 40, P) * (rng.random(P) < 0.7)).astype(np.int32)
+    grad = rng.standard_normal((P, 3)).astype(np.float32)
+    acc = rng.random((P, 1)).astype(np.float32)
+    den = rng.integers(0, 5, (P, 1)).astype(np.float32)
+    mx = (rng.random(P) * 30).astype(np.float32)
+    t = lambda a: torch.tensor(a, device="cuda:0")
+    tr, tg, ta, td, tm = t(radii), t(grad), t(acc), t(den), t(mx)
+    add_densification_stats(tr, tg, ta, td, tm)
+    ra, rd, rm = oracle.densify_stats(radii, grad, acc, den, mx)
+    assert np.array_equal(td.cpu().numpy(), rd) and np.array_equal(tm.cpu().numpy(), rm)
+    assert np.allclose(ta.cpu().numpy(), ra, rtol=1e-6, atol=0)
+    # the reference's own formulation in torch
+    vf = (tr > 0).nonzero()
+    ma, mdn, mm = t(acc), t(den), t(mx)
+    mm[vf] = torch.max(mm[vf], tr[vf].float())
+    ma[vf] += torch.norm(tg[vf, :2], dim=-1, keepdim=True)
+    mdn[vf] += 1
+    assert torch.equal(mm, tm) and torch.equal(mdn, td)
+    assert torch.allclose(ma, ta, rtol=1e-6, atol=0)
