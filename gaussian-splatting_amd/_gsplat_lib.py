@@ -28,7 +28,8 @@ class GsrScene(C.Structure):
 class GsrForwardOut(C.Structure):
     _fields_ = [(n, _vp) for n in ("out_color", "out_invdepth", "radii", "accum_alpha", "gauss_sum", "gauss_count",
                                    "last_contr_gauss", "out_depths", "out_reps")] + \
-               [("geom_buffer", _vp), ("geom_bytes", C.c_size_t), ("image_buffer", _vp), ("image_bytes", C.c_size_t)]
+               [("geom_buffer", _vp), ("geom_bytes", C.c_size_t), ("image_buffer", _vp), ("image_bytes", C.c_size_t),
+                ("num_visible", C.c_int64)]
 
 
 class GsrBackwardIO(C.Structure):

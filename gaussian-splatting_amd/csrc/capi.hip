@@ -56,11 +56,12 @@ size_t gsr_binning_bytes(int64_t R) { return bin_view(nullptr, (size_t)(R > 0 ? 
 size_t gsr_backward_work_bytes(int P) { return align_up((size_t)(P > 0 ? P : 1) * sizeof(GradRec), 256); }
 size_t gsr_sort_temp_bytes(int64_t n) { return sort_temp_view(nullptr, (size_t)(n > 0 ? n : 1), SORT_MAX_PASSES).bytes; }
 
-int gsr_forward_stage1(const GsrScene* s, const GsrForwardOut* o, void* stream, int64_t* num_rendered) {
+int gsr_forward_stage1(const GsrScene* s, GsrForwardOut* o, void* stream, int64_t* num_rendered) {
     int rc = check_scene(s);
     if (rc != GSR_OK) return rc;
     if (!o || !num_rendered) return GSR_ERR_ARG;
     *num_rendered = 0;
+    o->num_visible = 0;
     if (s->P == 0) return GSR_OK;
     if (!o->radii || !o->out_depths || !o->geom_buffer) return GSR_ERR_ARG;
     if (o->geom_bytes < gsr_geom_bytes(s->P)) return GSR_ERR_BUFFER;
@@ -70,13 +71,14 @@ int gsr_forward_stage1(const GsrScene* s, const GsrForwardOut* o, void* stream, 
     mark(s, GSR_EV_STAGE1_BEGIN, st);
     GSR_TRY(launch_preprocess_fwd(*s, *o, g, st));
     mark(s, GSR_EV_PREPROCESS, st);
-    GSR_TRY(launch_scan_blocks(g.block_sums, (s->P + PRE_BLOCK - 1) / PRE_BLOCK, g.total, st));
+    GSR_TRY(launch_scan_blocks(g, (s->P + PRE_BLOCK - 1) / PRE_BLOCK, st));
     mark(s, GSR_EV_SCAN, st);
-    uint64_t tot[2] = {0, 0};
+    uint64_t tot[3] = {0, 0, 0};
     if (hipMemcpyAsync(tot, g.total, sizeof(tot), hipMemcpyDeviceToHost, st) != hipSuccess) return GSR_ERR_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return GSR_ERR_HIP;
     if (tot[1]) return GSR_ERR_OVERFLOW;
     *num_rendered = (int64_t)tot[0];
+    o->num_visible = (int64_t)tot[2];
     return GSR_OK;
 }
 
@@ -110,9 +112,11 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
         mark(s, GSR_EV_STAGE2_BEGIN, st);
         if (R > 0) {
             int ord = 0;
-            GSR_TRY(launch_depth_order(g, s->P, st, &ord));
+            // only the Gaussians with instances are ordered when stage 1 reported how many there are
+            const int n = (o->num_visible > 0 && o->num_visible <= s->P) ? (int)o->num_visible : s->P;
+            GSR_TRY(launch_depth_order(g, s->P, n, st, &ord));
             mark(s, GSR_EV_DEPTH_ORDER, st);
-            GSR_TRY(launch_emit_keys(*s, g, g.dvals[ord], b.keys[0], b.vals[0], st));
+            GSR_TRY(launch_emit_keys(*s, g, g.dvals[ord], n, b.keys[0], b.vals[0], st));
             mark(s, GSR_EV_EMIT, st);
             // emission order is (depth, index): the stable sort only has to order the tile ids
             GSR_TRY(launch_radix_sort_u32(b.keys, b.vals, R, 0, tile_bits(s->W, s->H), b.sort_temp, st, &res, false));

@@ -33,6 +33,7 @@ struct PreArgs {
     float2* gstat;
     uint8_t* clamped;
     uint32_t* block_sums;
+    uint32_t* vis_sums;
 };
 
 __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs a) {
@@ -107,9 +108,16 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs
     }
     // tiles touched by this block of 256 Gaussians
     const uint32_t ws = wave_sum_u32(tiles);
-    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = ws;
+    const uint32_t wv = (uint32_t)__popcll(__ballot(tiles > 0));
+    if ((threadIdx.x & 63) == 0) {
+        s_tmp[threadIdx.x >> 6] = ws;
+        s_tmp[4 + (threadIdx.x >> 6)] = wv;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) a.block_sums[blockIdx.x] = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+    if (threadIdx.x == 0) {
+        a.block_sums[blockIdx.x] = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+        a.vis_sums[blockIdx.x] = s_tmp[4] + s_tmp[5] + s_tmp[6] + s_tmp[7];
+    }
 }
 
 // Exclusive scan of the per-block sums, total instance count into total[0],
@@ -117,8 +125,12 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs
 // sums per thread and step, so 23 k sums (6 M Gaussians) take two steps; the
 // running values are 64-bit so that an overflowing total is detected, not wrapped.
 constexpr int SCAN_THREADS = 1024, SCAN_ITEMS = 16;
-__global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* block_sums, int nb, uint64_t* total) {
+// Workgroup 1, if launched, scans a second array the same way (the per-block
+// counts of Gaussians with instances) and writes its total into total[2].
+__global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* sums0, uint32_t* sums1, int nb,
+                                                                   uint64_t* total) {
     __shared__ uint64_t s_wave[SCAN_THREADS / 64];
+    uint32_t* block_sums = blockIdx.x == 0 ? sums0 : sums1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     uint64_t carry = 0;
     for (int base = 0; base < nb; base += SCAN_THREADS * SCAN_ITEMS) {
@@ -156,20 +168,44 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* blo
     }
     if (tid == 0) {
         block_sums[nb] = (uint32_t)carry;
-        total[0] = carry;
-        total[1] = carry >= (1ull << 30) ? 1 : 0;
+        if (blockIdx.x == 0) {
+            total[0] = carry;
+            total[1] = carry >= (1ull << 30) ? 1 : 0;
+        } else {
+            total[2] = carry;
+        }
     }
 }
 
 // Depth keys for ordering the Gaussians front to back: the f32 bits of the
 // view-space depth (positive floats order like their bit patterns), all ones
 // for Gaussians that produce no instance so that they sort to the end.
-__global__ void __launch_bounds__(256) depth_keys_kernel(int P, const uint4* bin, uint32_t* keys, uint32_t* vals) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    const uint4 b = bin[i];
-    keys[i] = b.w ? b.z : 0xFFFFFFFFu;
-    vals[i] = (uint32_t)i;
+__global__ void __launch_bounds__(PRE_BLOCK) depth_keys_kernel(int P, const uint4* bin, const uint32_t* vis_off,
+                                                               uint32_t* keys, uint32_t* vals) {
+    // vis_off == null: one pair per Gaussian (those without instances get the largest key).
+    // Otherwise only Gaussians with instances get a pair, packed in index order: a block's pairs
+    // start at vis_off[block] (blocks = the preprocess blocks that counted them).
+    __shared__ uint32_t s_w[4];
+    const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    const uint4 b = i < P ? bin[i] : make_uint4(0, 0, 0, 0);
+    if (!vis_off) {
+        if (i < P) {
+            keys[i] = b.w ? b.z : 0xFFFFFFFFu;
+            vals[i] = (uint32_t)i;
+        }
+        return;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t m = __ballot(b.w > 0);
+    if (lane == 0) s_w[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t base = vis_off[blockIdx.x];
+    for (int k = 0; k < w; ++k) base += s_w[k];
+    if (b.w > 0) {
+        const uint32_t dst = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        keys[dst] = b.z;
+        vals[dst] = (uint32_t)i;
+    }
 }
 
 // The tile rectangles in depth order: sbin[i] = {rect origin, rect size, Gaussian
@@ -292,31 +328,34 @@ hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, cons
     a.radii = o.radii; a.out_depths = o.out_depths;
     a.rec = g.rec; a.cov3D = g.cov3D; a.bin = g.bin; a.gstat = g.gstat; a.clamped = g.clamped;
     a.block_sums = g.block_sums;
+    a.vis_sums = g.vis_sums;
     const int nb = (s.P + PRE_BLOCK - 1) / PRE_BLOCK;
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, a);
     return hipGetLastError();
 }
 
-hipError_t launch_scan_blocks(uint32_t* block_sums, int nb, uint64_t* total, hipStream_t st) {
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, block_sums, nb, total);
+hipError_t launch_scan_blocks(const GeomBuf& g, int nb, hipStream_t st) {
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(2), dim3(SCAN_THREADS), 0, st, g.block_sums, g.vis_sums, nb, g.total);
     return hipGetLastError();
 }
 
-hipError_t launch_depth_order(const GeomBuf& g, int P, hipStream_t st, int* order_buffer) {
-    hipLaunchKernelGGL(depth_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, g.bin, g.dkeys[0], g.dvals[0]);
+hipError_t launch_depth_order(const GeomBuf& g, int P, int n, hipStream_t st, int* order_buffer) {
+    hipLaunchKernelGGL(depth_keys_kernel, dim3((P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, st, P, g.bin,
+                       n < P ? g.vis_sums : (const uint32_t*)nullptr, g.dkeys[0], g.dvals[0]);
     uint32_t* k[2] = {g.dkeys[0], g.dkeys[1]};
     uint32_t* v[2] = {g.dvals[0], g.dvals[1]};
-    return launch_radix_sort_u32(k, v, P, 0, 32, g.dsort_temp, st, order_buffer, false);
+    return launch_radix_sort_u32(k, v, n, 0, 32, g.dsort_temp, st, order_buffer, false);
 }
 
-hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, const uint32_t* order, uint32_t* keys, uint32_t* vals,
-                            hipStream_t st) {
-    const int nb = (s.P + PRE_BLOCK - 1) / PRE_BLOCK;
+hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, const uint32_t* order, int n, uint32_t* keys,
+                            uint32_t* vals, hipStream_t st) {
+    const int nb = (n + PRE_BLOCK - 1) / PRE_BLOCK;
     const int grid_x = (s.W + TILE_X - 1) / TILE_X;
-    hipLaunchKernelGGL(order_gather_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, s.P, order, g.bin, g.sbin, g.order_sums);
-    // total[] was read by the host already; the scan rewrites the same value
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, g.order_sums, nb, g.total);
-    hipLaunchKernelGGL(emit_keys_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, s.P, grid_x, g.sbin, g.order_sums, keys,
+    hipLaunchKernelGGL(order_gather_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, n, order, g.bin, g.sbin, g.order_sums);
+    // total[0..1] were read by the host already; the scan rewrites the same values
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, g.order_sums, (uint32_t*)nullptr, nb,
+                       g.total);
+    hipLaunchKernelGGL(emit_keys_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, n, grid_x, g.sbin, g.order_sums, keys,
                        vals);
     return hipGetLastError();
 }

@@ -17,7 +17,8 @@ struct GeomBuf {
     float2* gstat;        // [P] (sum of T, hit count as float), accumulated by the forward blend
     uint8_t* clamped;     // [P]
     uint32_t* block_sums; // [nblocks+1] tiles per block of 256 Gaussians in index order (gives the total)
-    uint64_t* total;      // [2]
+    uint32_t* vis_sums;   // [nblocks+1] Gaussians with instances per block, then exclusive offsets
+    uint64_t* total;      // [4] instances, overflow flag, Gaussians with instances
     uint32_t* dkeys[2];   // [P] depth bits (all ones for Gaussians that are not rendered), ping-pong
     uint32_t* dvals[2];   // [P] Gaussian index, ping-pong; the sorted one is the front-to-back order
     uint4* sbin;          // [P] {x0 | y0<<16, w | h<<16, Gaussian index, tiles} in front-to-back order
@@ -38,7 +39,8 @@ inline GeomBuf geom_buf(const void* base, size_t P) {
     v.gstat = (float2*)take(P * sizeof(float2));
     v.clamped = (uint8_t*)take(P);
     v.block_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));
-    v.total = (uint64_t*)take(2 * sizeof(uint64_t));
+    v.vis_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));
+    v.total = (uint64_t*)take(4 * sizeof(uint64_t));
     v.dkeys[0] = (uint32_t*)take(P * sizeof(uint32_t));
     v.dkeys[1] = (uint32_t*)take(P * sizeof(uint32_t));
     v.dvals[0] = (uint32_t*)take(P * sizeof(uint32_t));
@@ -63,12 +65,14 @@ static_assert(sizeof(GradRec) == 64, "GradRec must be 64 bytes");
 int sort_passes_for(int begin_bit, int end_bit);
 
 hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, const GeomBuf& g, hipStream_t st);
-hipError_t launch_scan_blocks(uint32_t* block_sums, int nb, uint64_t* total, hipStream_t st);
-// Depth keys of all Gaussians, sorted front to back (stable): g.dvals[*order_buffer] is the order.
-hipError_t launch_depth_order(const GeomBuf& g, int P, hipStream_t st, int* order_buffer);
+// Exclusive scans of the per-block tile sums and visible counts; totals into g.total.
+hipError_t launch_scan_blocks(const GeomBuf& g, int nb, hipStream_t st);
+// Depth keys of the n Gaussians to order (n = number with instances: compacted; n = P: all of them),
+// sorted front to back (stable): g.dvals[*order_buffer][0..n) is the order.
+hipError_t launch_depth_order(const GeomBuf& g, int P, int n, hipStream_t st, int* order_buffer);
 // Key emission in depth order: (tile id, Gaussian index) pairs; only the tile remains to be sorted on.
-hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, const uint32_t* order, uint32_t* keys, uint32_t* vals,
-                            hipStream_t st);
+hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, const uint32_t* order, int n, uint32_t* keys,
+                            uint32_t* vals, hipStream_t st);
 hipError_t launch_tile_ranges(const uint32_t* keys, int64_t R, uint2* ranges, int ntiles, hipStream_t st);
 // (tile << 32 | depth bits) of every sorted instance, as the reference's sort keys.
 hipError_t launch_keys64(const GeomBuf& g, const uint32_t* tile_keys, const uint32_t* point_list, int64_t R,

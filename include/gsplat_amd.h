@@ -124,6 +124,9 @@ typedef struct {
     size_t geom_bytes;
     void* image_buffer;      /* device, >= gsr_image_bytes(W,H) */
     size_t image_bytes;
+    int64_t num_visible;     /* written by gsr_forward_stage1, read by gsr_forward_stage2 (same struct): Gaussians
+                                that produce at least one instance; stage 2 orders only those by depth.  A value
+                                < 0 there means "not known" and all P are ordered. */
 } GsrForwardOut;
 
 /* Gradients.  Inputs are the three per-pixel gradients; every output is fully
@@ -157,7 +160,7 @@ size_t gsr_backward_work_bytes(int P);
 
 /* Preprocess + prefix sum.  Blocks the host once (as the reference does,
  * rasterizer_impl.cu:338-346) to return the instance count in *num_rendered. */
-int gsr_forward_stage1(const GsrScene* scene, const GsrForwardOut* out, void* stream, int64_t* num_rendered);
+int gsr_forward_stage1(const GsrScene* scene, GsrForwardOut* out, void* stream, int64_t* num_rendered);
 
 /* Key emission, sort, tile ranges, blending.  binning_buffer must hold
  * gsr_binning_bytes(num_rendered) and be kept for the backward pass. */
