@@ -7,8 +7,9 @@
 // reads.  A wave whose 64 pixels are all saturated stops computing (ballot);
 // the workgroup stops when its four waves have.  The per-Gaussian statistics
 // of the fork (sum of transmittance and hit count, forward.cu:431-432) are
-// reduced over the wave with DPP adds, over the four waves through LDS, and
-// leave the workgroup as one pair of adjacent float atomics per instance.
+// reduced over the wave 16 instances at a time by a transposing DPP butterfly,
+// over the four waves through LDS, and leave the workgroup as one pair of
+// adjacent float atomics per instance.
 #include "kernels.h"
 
 namespace gs {
@@ -84,14 +85,24 @@ __global__ void __launch_bounds__(TILE_PIX) render_fwd_kernel(const RenderFwdArg
         __syncthreads();
 
         bool wave_done = __ballot(!done) == 0;
+        // Instances in groups of 16: the transmittance a lane contributes to each instance's
+        // statistic waits in a register and one transposing reduction per group sums all 16 over
+        // the wave (17 lane exchanges per group instead of 6 per instance).
 #pragma unroll 1
-        for (int k = 0; k < 4; ++k) {
-            float acc_s = 0.f, acc_c = 0.f;
-            const int jend = min(64, nb - k * 64);
-            if (!wave_done) {
-#pragma unroll 1
-                for (int jj = 0; jj < jend; ++jj) {
-                    const int j = k * 64 + jj;
+        for (int j0 = 0; j0 < nb; j0 += 16) {
+            if (wave_done) {  // nothing left for this wave: its share of the remaining statistics is zero
+                if (lane < 16) s_gsum[w][j0 + lane] = s_gcnt[w][j0 + lane] = 0.f;
+                continue;
+            }
+            float tv[16];
+            float acc_c = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) tv[u] = 0.f;
+            {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int j = j0 + u;
+                    if (wave_done || j >= nb) continue;
                     const float4 q0 = s_q0[j];
                     const float4 q1 = s_q1[j];
                     const V2 xy = {q0.x, q0.y};
@@ -101,10 +112,8 @@ __global__ void __launch_bounds__(TILE_PIX) render_fwd_kernel(const RenderFwdArg
                     const bool hit = !done && !(power > 0.0f);
                     const uint64_t hm = __ballot(hit);
                     if (hm == 0) continue;
-                    const float S = wave_sum(hit ? T : 0.0f);
-                    const float cnt = (float)__popcll(hm);
-                    acc_s = (lane == jj) ? S : acc_s;
-                    acc_c = (lane == jj) ? cnt : acc_c;
+                    tv[u] = hit ? T : 0.0f;
+                    acc_c = (lane == u) ? (float)__popcll(hm) : acc_c;
 
                     const float alpha = fmin_(GS_ALPHA_MAX, co.w * gs_expf(power));
                     const bool pass = hit && !(alpha < GS_ALPHA_MIN);
@@ -131,14 +140,14 @@ __global__ void __launch_bounds__(TILE_PIX) render_fwd_kernel(const RenderFwdArg
                             last_g = (int)s_id[j];
                         }
                     }
-                    if (__ballot(!done) == 0) {
-                        wave_done = true;
-                        break;
-                    }
+                    if (__ballot(!done) == 0) wave_done = true;
                 }
             }
-            s_gsum[w][k * 64 + lane] = acc_s;
-            s_gcnt[w][k * 64 + lane] = acc_c;
+            const float tot = rows_sum4(row_transpose_sum16(tv, lane));
+            if (lane < 16) {
+                s_gsum[w][j0 + lane] = tot;
+                s_gcnt[w][j0 + lane] = acc_c;
+            }
         }
         if (lane == 0) s_wdone[w] = wave_done ? 1 : 0;
         __syncthreads();
