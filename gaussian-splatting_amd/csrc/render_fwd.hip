@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(TILE_PIX) render_fwd_kernel(const RenderFwdArg
     __shared__ float4 s_q2[TILE_PIX];  // b, 1/depth, rep0, rep1
     __shared__ float4 s_q3[TILE_PIX];  // rep2, rep3, depth, -
     __shared__ uint32_t s_id[TILE_PIX];
+    __shared__ float s_tau[TILE_PIX];  // power below which alpha < 1/255 for certain
     __shared__ float s_gsum[4][TILE_PIX];
     __shared__ float s_gcnt[4][TILE_PIX];
     __shared__ int s_wdone[4];
@@ -81,6 +82,9 @@ __global__ void __launch_bounds__(TILE_PIX) render_fwd_kernel(const RenderFwdArg
             s_q1[tid] = r4[1];
             s_q2[tid] = r4[2];
             if (DIM > 2) s_q3[tid] = r4[3];
+            // alpha = opacity * exp(power) >= 1/255  <=>  power >= -log(255 * opacity); the margin covers the
+            // rounding of the fast logarithm and of the exponential by orders of magnitude
+            s_tau[tid] = -__logf(255.0f * s_q1[tid].y) - 0.01f;
         }
         __syncthreads();
 
@@ -114,6 +118,7 @@ __global__ void __launch_bounds__(TILE_PIX) render_fwd_kernel(const RenderFwdArg
                     if (hm == 0) continue;
                     tv[u] = hit ? T : 0.0f;
                     acc_c = (lane == u) ? (float)__popcll(hm) : acc_c;
+                    if (__ballot(hit && power >= s_tau[j]) == 0) continue;  // no pixel of the wave can pass the alpha test
 
                     const float alpha = fmin_(GS_ALPHA_MAX, co.w * gs_expf(power));
                     const bool pass = hit && !(alpha < GS_ALPHA_MIN);
