@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
     __shared__ float4 s_q2[TILE_PIX];
     __shared__ float4 s_q3[TILE_PIX];
     __shared__ uint32_t s_id[TILE_PIX];
+    __shared__ float s_tau[TILE_PIX];  // power below which alpha < 1/255 for certain
     __shared__ float s_acc[TILE_PIX][16];
     __shared__ uint32_t s_max[4];
 
@@ -104,6 +105,8 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
             s_q1[tid] = r4[1];
             s_q2[tid] = r4[2];
             if (DIM > 2) s_q3[tid] = r4[3];
+            // alpha = opacity * exp(power) >= 1/255  <=>  power >= -log(255 * opacity), with a wide margin
+            s_tau[tid] = -__logf(255.0f * s_q1[tid].y) - 0.01f;
         }
         {
             float4* z = reinterpret_cast<float4*>(&s_acc[tid][0]);
@@ -121,7 +124,7 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
             float dx, dy;
             const float power = splat_power(xy, pxf, pyf, co, &dx, &dy);
             bool valid = inside && contributor < last_contributor && !(power > 0.0f);
-            if (__ballot(valid) == 0) continue;
+            if (__ballot(valid && power >= s_tau[j]) == 0) continue;  // nobody can pass the alpha test
             const float G = gs_expf(power);
             const float alpha = fmin_(GS_ALPHA_MAX, co.w * G);
             valid = valid && !(alpha < GS_ALPHA_MIN);
