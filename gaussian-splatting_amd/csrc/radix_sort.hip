@@ -80,7 +80,7 @@ __device__ __forceinline__ uint32_t block_scan_excl_256_nw(uint32_t v, uint32_t*
 // One pass over one tile of SORT_TILE = THREADS * ITEMS pairs.  LDS: an
 // 8-byte-per-pair staging area (u64 keys first and then, once they have left,
 // the values; u32 keys and values side by side in one phase), per-wave digit
-// counters and three 256-entry tables; about 37 KiB.
+// counters and three 256-entry tables; about 41 KiB with 8 waves of 8 keys per lane (78 VGPRs, 6 waves/SIMD).
 #ifndef GS_OS_BLOCKS
 #define GS_OS_BLOCKS 2
 #endif
@@ -257,7 +257,7 @@ onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* 
 }
 
 #ifndef GS_OS_THREADS
-#define GS_OS_THREADS 256
+#define GS_OS_THREADS 512
 #endif
 constexpr int OS_THREADS = GS_OS_THREADS;
 constexpr int OS_ITEMS = SORT_TILE / OS_THREADS;
