@@ -20,9 +20,6 @@ constexpr uint32_t SPIN_LIMIT = 1u << 22;
 #ifndef GS_LOOK_BATCH
 #define GS_LOOK_BATCH 4
 #endif
-#ifndef GS_LOOK_PREFETCH
-#define GS_LOOK_PREFETCH 1
-#endif
 constexpr int LOOK_BATCH = GS_LOOK_BATCH;
 
 int sort_passes_for(int begin_bit, int end_bit) { return (end_bit - begin_bit + 7) / 8; }

@@ -43,9 +43,9 @@ def test_size_queries_and_layout():
     offs = [lay.rec, lay.cov3D, lay.tiles, lay.clamped, lay.block_sums, lay.total]
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
     assert lay.keys0 < lay.keys1 < lay.vals0 < lay.vals1
-    # 82 x 53 tiles -> 13 tile bits -> 45 key bits -> 6 passes -> result in buffer 0
+    # 82 x 53 tiles -> 13 tile bits -> 2 passes over the tile ids -> result in buffer 0
     assert lay.sorted_buffer == 0
-    assert L.gsr_layout(10, 16, 16, 0, C.byref(lay)) == 0 and lay.sorted_buffer == 1  # 33 bits -> 5 passes
+    assert L.gsr_layout(10, 16, 16, 0, C.byref(lay)) == 0 and lay.sorted_buffer == 1  # 1 tile bit -> 1 pass
 
 
 def test_argument_validation_without_gpu():

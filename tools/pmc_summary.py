@@ -16,7 +16,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "pmc")
 KERNEL_KEYS = {  # kernel symbol substring -> bench.py kernel name
-    "preprocess_fwd_kernel": "preprocess", "depth_keys_kernel": "depth_order:keys", "order_sums_kernel": "depth_order:sums",
+    "preprocess_fwd_kernel": "preprocess", "depth_keys_kernel": "depth_order:keys", 
     "emit_keys_kernel": "emit_keys", "onesweep_kernel": "sort:onesweep", "sort_hist_kernel": "sort:hist",
     "sort_scan_hist_kernel": "sort:scan", "tile_ranges_kernel": "tile_ranges", "render_fwd_kernel": "render_fwd",
     "render_bwd_kernel": "render_bwd", "preprocess_bwd_kernel": "preprocess_bwd",
