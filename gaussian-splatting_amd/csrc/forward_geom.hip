@@ -1,6 +1,7 @@
 // Per-Gaussian forward stages: preprocess (cull, EWA projection, conic, radius,
-// tile rectangle, SH -> RGB), the prefix sum over touched tiles, key emission
-// and tile-range detection.  Reference: cuda_rasterizer/forward.cu:151-308,
+// tile rectangle, SH -> RGB), the prefix sums over touched tiles and visible
+// Gaussians, the front-to-back ordering of the visible Gaussians, key emission
+// in that order and tile-range detection.  Reference: cuda_rasterizer/forward.cu:151-308,
 // rasterizer_impl.cu:54-137, 326-400.
 //
 // HBM-bound stages.  One thread per Gaussian; the per-Gaussian results that the

@@ -7,10 +7,9 @@
 // summed over the wave's 64 pixels by a transposing DPP butterfly (15 lane
 // exchanges) and two row swaps, over the four waves by LDS atomics (16 lanes,
 // 16 different words: an LDS atomic whose lanes share a word serialises), and
-// leave the workgroup once
-// per (tile, instance) as a 64-byte GradRec update: 16 lanes add to 16
-// consecutive floats, so one wave instruction carries four complete line-half
-// atomics instead of 64 scattered ones.
+// leave the workgroup once per (tile, instance) as a 64-byte GradRec update:
+// 16 lanes add to 16 consecutive floats, so one wave instruction carries four
+// complete line-half atomics instead of 64 scattered ones.
 #include "kernels.h"
 
 namespace gs {
