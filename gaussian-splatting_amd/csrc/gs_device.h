@@ -74,19 +74,66 @@ __device__ __forceinline__ float lane_xor4(float v) {
 
 // Transposing reduction of 16 per-lane values over a row of 16 lanes: on return
 // lane l holds the sum over its row of v[l & 15].  Each butterfly step halves
-// the number of live registers (a lane keeps the half whose index bit matches
-// its own lane bit and adds the partner's copy), 15 exchanges in all instead
-// of the 64 a value-by-value reduction needs.
+// the number of live registers: a lane keeps the half whose index bit matches
+// one of its lane bits and adds the partner lane's copy.  The two big steps use
+// lane bits 3 and 2, which are *bank* bits of the DPP control (a bank is four
+// lanes): a v_add_f32_dpp restricted by bank_mask writes only the lanes that
+// keep that half, so a pair of values folds in two instructions with no select.
+// The two small steps (lane bits 1 and 0, inside a bank) select and add.
+// 33 instructions in all, where a value-by-value reduction needs 64.
+// The asm blocks start with the wait states a DPP read of a just-written VGPR
+// needs (the compiler does not see inside them).
 __device__ __forceinline__ float row_transpose_sum16(const float (&v)[16], int lane) {
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    // lane bit 3 picks index bit 0, bit 2 picks bit 1, bit 1 picks bit 2, bit 0 picks bit 3:
+    // feed the values in bit-reversed order so that lane l ends up with v[l].
     float a[8], b[4], c[2];
+#define GS_FOLD3(i, lo, hi) \
+    "v_add_f32_dpp %" #i ", %" #lo ", %" #lo " row_ror:8 row_mask:0xf bank_mask:0x3\n\t" \
+    "v_add_f32_dpp %" #i ", %" #hi ", %" #hi " row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+    asm("s_nop 1\n\t"
+        GS_FOLD3(0, 8, 9) GS_FOLD3(1, 10, 11) GS_FOLD3(2, 12, 13) GS_FOLD3(3, 14, 15)
+        GS_FOLD3(4, 16, 17) GS_FOLD3(5, 18, 19) GS_FOLD3(6, 20, 21) GS_FOLD3(7, 22, 23)
+        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
+        : "v"(v[0]), "v"(v[8]), "v"(v[4]), "v"(v[12]), "v"(v[2]), "v"(v[10]), "v"(v[6]), "v"(v[14]),
+          "v"(v[1]), "v"(v[9]), "v"(v[5]), "v"(v[13]), "v"(v[3]), "v"(v[11]), "v"(v[7]), "v"(v[15]));
+#undef GS_FOLD3
+#define GS_FOLD2(i, lo, hi) \
+    "v_add_f32_dpp %" #i ", %" #lo ", %" #lo " row_shl:4 row_mask:0xf bank_mask:0x5\n\t" \
+    "v_add_f32_dpp %" #i ", %" #hi ", %" #hi " row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+    asm("s_nop 1\n\t"
+        GS_FOLD2(0, 4, 5) GS_FOLD2(1, 6, 7) GS_FOLD2(2, 8, 9) GS_FOLD2(3, 10, 11)
+        : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+#undef GS_FOLD2
+    const bool b0 = lane & 1, b1 = lane & 2;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = (b0 ? v[2 * i + 1] : v[2 * i]) + lane_xor1(b0 ? v[2 * i] : v[2 * i + 1]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b[i] = (b1 ? a[2 * i + 1] : a[2 * i]) + lane_xor2(b1 ? a[2 * i] : a[2 * i + 1]);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) c[i] = (b2 ? b[2 * i + 1] : b[2 * i]) + lane_xor4(b2 ? b[2 * i] : b[2 * i + 1]);
-    return (b3 ? c[1] : c[0]) + lane_xor8(b3 ? c[0] : c[1]);
+    for (int i = 0; i < 2; ++i) c[i] = (b1 ? b[2 * i + 1] : b[2 * i]) + lane_xor2(b1 ? b[2 * i] : b[2 * i + 1]);
+    return (b0 ? c[1] : c[0]) + lane_xor1(b0 ? c[0] : c[1]);
+}
+
+// Lane masks.  A ballot of a direct comparison is one v_cmp into an SGPR pair, and a
+// wave-uniform mask turns back into a per-lane predicate for free (the hardware predicate
+// *is* such a mask).  Keeping per-lane flags as 64-bit masks and combining them with scalar
+// and / andn2 avoids the v_cndmask + v_cmp pair the compiler emits for a ballot of a
+// boolean expression.
+__device__ __forceinline__ uint64_t lanes_where(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool lane_in(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+// gs_expf for the blend kernels: no clamps (callers only use the result on lanes whose
+// argument is in [-87, 0]) and the scaling by 2^n as one v_ldexp.  Same roundings as gs_expf
+// on that interval.
+__device__ __forceinline__ float gs_expf_blend(float x) {
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.428606765330187045e-06f, r);
+    float p = 0.000198527617612853646278381f;
+    p = fmaf(p, r, 0.00139304355252534151077271f);
+    p = fmaf(p, r, 0.00833336077630519866943359f);
+    p = fmaf(p, r, 0.0416664853692054748535156f);
+    p = fmaf(p, r, 0.166666671633720397949219f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(r * r, p, r) + 1.0f;
+    return __builtin_amdgcn_ldexpf(p, (int)n);
 }
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0)); }

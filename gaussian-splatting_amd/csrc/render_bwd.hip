@@ -33,14 +33,15 @@ __device__ __forceinline__ int xcd_remap_b(int b, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 template <int DIM, bool INVD>
 __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArgs a) {
-    __shared__ float4 s_q0[TILE_PIX];
-    __shared__ float4 s_q1[TILE_PIX];
-    __shared__ float4 s_q2[TILE_PIX];
-    __shared__ float4 s_q3[TILE_PIX];
-    __shared__ uint32_t s_id[TILE_PIX];
-    __shared__ float s_tau[TILE_PIX];  // power below which alpha < 1/255 for certain
+    // same regrouping of the SplatRec as in the forward kernel
+    __shared__ float4 s_q0[TILE_PIX];  // x, y, conic.x, conic.y
+    __shared__ float4 s_q1[TILE_PIX];  // conic.z, tau, opacity, Gaussian index (bits)
+    __shared__ float4 s_q2[TILE_PIX];  // r, g, b, 1/depth
+    __shared__ float4 s_q3[TILE_PIX];  // rep0 .. rep3
     __shared__ float s_acc[TILE_PIX][16];
     __shared__ uint32_t s_max[4];
 
@@ -59,24 +60,24 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
     float T = T_final;
     const uint32_t last_contributor = inside ? a.n_contrib[pid] : 0u;
 
-    float dpix0 = 0.f, dpix1 = 0.f, dpix2 = 0.f, dinvd = 0.f;
-    float drep[DIM > 0 ? DIM : 1];
-#pragma unroll
-    for (int i = 0; i < (DIM > 0 ? DIM : 1); ++i) drep[i] = 0.f;
+    // dL/d(pixel) in the pairing of s_q2 / s_q3: (r, g), (b, 1/depth), reps
+    f2 D01 = {0.f, 0.f}, D2i = {0.f, 0.f}, E01 = {0.f, 0.f}, E23 = {0.f, 0.f};
     if (inside) {
-        dpix0 = a.dL_dpix[pid];
-        dpix1 = a.dL_dpix[HW + pid];
-        dpix2 = a.dL_dpix[2 * HW + pid];
+        D01.x = a.dL_dpix[pid];
+        D01.y = a.dL_dpix[HW + pid];
+        D2i.x = a.dL_dpix[2 * HW + pid];
+        if (INVD) D2i.y = a.dL_dinvdepth[pid];
         if (DIM == 4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) drep[i] = a.dL_dreps[i * HW + pid];
+            E01.x = a.dL_dreps[pid];
+            E01.y = a.dL_dreps[HW + pid];
+            E23.x = a.dL_dreps[2 * HW + pid];
+            E23.y = a.dL_dreps[3 * HW + pid];
         }
-        if (INVD) dinvd = a.dL_dinvdepth[pid];
     }
     float bg_dot_dpixel = 0;
-    bg_dot_dpixel += a.bg[0] * dpix0;
-    bg_dot_dpixel += a.bg[1] * dpix1;
-    bg_dot_dpixel += a.bg[2] * dpix2;
+    bg_dot_dpixel += a.bg[0] * D01.x;
+    bg_dot_dpixel += a.bg[1] * D01.y;
+    bg_dot_dpixel += a.bg[2] * D2i.x;
 
     float accum_S = 0.f, last_S = 0.f, last_alpha = 0.f;
 
@@ -99,13 +100,16 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
         if (tid < nb) {
             const uint32_t id = a.point_list[range.x + (uint32_t)(max_last - 1 - base - tid)];
             const float4* r4 = reinterpret_cast<const float4*>(a.rec + id);
-            s_id[tid] = id;
-            s_q0[tid] = r4[0];
-            s_q1[tid] = r4[1];
-            s_q2[tid] = r4[2];
-            if (DIM > 2) s_q3[tid] = r4[3];
-            // alpha = opacity * exp(power) >= 1/255  <=>  power >= -log(255 * opacity), with a wide margin
-            s_tau[tid] = -__logf(255.0f * s_q1[tid].y) - 0.01f;
+            const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
+            s_q0[tid] = r0;
+            // tau as in the forward kernel: power below it cannot reach alpha >= 1/255; never below -87
+            const float tau = fmaxf(-__logf(255.0f * r1.y) - 0.01f, -87.0f);
+            s_q1[tid] = make_float4(r1.x, tau, r1.y, __uint_as_float(id));
+            s_q2[tid] = make_float4(r1.z, r1.w, r2.x, r2.y);
+            if (DIM > 2) {
+                const float4 r3 = r4[3];
+                s_q3[tid] = make_float4(r2.z, r2.w, r3.x, r3.y);
+            }
         }
         {
             float4* z = reinterpret_cast<float4*>(&s_acc[tid][0]);
@@ -118,55 +122,50 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
             const uint32_t contributor = (uint32_t)(max_last - 1 - base - j);
             const float4 q0 = s_q0[j];
             const float4 q1 = s_q1[j];
+            asm volatile("" : : "v"(q1.y), "v"(q1.z));  // one 16-byte LDS read
             const V2 xy = {q0.x, q0.y};
-            const V4 co = {q0.z, q0.w, q1.x, q1.y};
+            const V4 co = {q0.z, q0.w, q1.x, q1.z};
             float dx, dy;
             const float power = splat_power(xy, pxf, pyf, co, &dx, &dy);
-            bool valid = inside && contributor < last_contributor && !(power > 0.0f);
-            if (__ballot(valid && power >= s_tau[j]) == 0) continue;  // nobody can pass the alpha test
-            const float G = gs_expf(power);
-            const float alpha = fmin_(GS_ALPHA_MAX, co.w * G);
-            valid = valid && !(alpha < GS_ALPHA_MIN);
-            if (__ballot(valid) == 0) continue;
+            // backward.cu:592-611 as lane masks; pixels outside the image have last_contributor 0
+            const uint64_t hm = lanes_where(contributor < last_contributor) & lanes_where(!(power > 0.0f));
+            const uint64_t pm = lanes_where(power >= q1.y) & hm;
+            if (pm == 0) continue;  // nobody can pass the alpha test
+            const float G = gs_expf_blend(power);  // lanes outside pm compute values nobody reads
+            const float alpha = __builtin_fminf(GS_ALPHA_MAX, co.w * G);
+            const uint64_t vm = lanes_where(!(alpha < GS_ALPHA_MIN)) & pm;
+            if (vm == 0) continue;
 
             const float4 q2 = s_q2[j];
             float4 q3 = make_float4(0, 0, 0, 0);
             if (DIM == 4) q3 = s_q3[j];
 
             float g_mx = 0.f, g_my = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_op = 0.f;
-            float g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, g_id = 0.f;
-            float g_rep[DIM > 0 ? DIM : 1];
-#pragma unroll
-            for (int i = 0; i < (DIM > 0 ? DIM : 1); ++i) g_rep[i] = 0.f;
+            f2 g_rg = {0.f, 0.f}, g_bd = {0.f, 0.f}, g_r01 = {0.f, 0.f}, g_r23 = {0.f, 0.f};
 
-            if (valid) {
+            if (lane_in(vm)) {
                 // 1 / (1 - alpha) by v_rcp_f32 (1 ulp): the gradients are sums of atomics anyway, and an
-                // IEEE divide is ten instructions of the ~120 in this body.
+                // IEEE divide is ten instructions of the ~100 in this body.
                 const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
                 T = T * inv_1ma;
                 const float dchannel_dcolor = alpha * T;
+                const f2 dc2 = {dchannel_dcolor, dchannel_dcolor};
                 // The reference keeps, per channel, accum = last_alpha * last_c + (1 - last_alpha) * accum
                 // and adds (c - accum) * dL_dpixel over the channels (backward.cu:618-660).  Only the
                 // sum is used, and it obeys the same recurrence with S = sum_ch c * dL_dpixel in the
-                // place of c: two scalars of state per pixel instead of two per channel.
-                float S = q1.z * dpix0;
-                S = fmaf(q1.w, dpix1, S);
-                S = fmaf(q2.x, dpix2, S);
-                g_c0 = dchannel_dcolor * dpix0;
-                g_c1 = dchannel_dcolor * dpix1;
-                g_c2 = dchannel_dcolor * dpix2;
+                // place of c: two scalars of state per pixel instead of two per channel.  S is summed
+                // two channels at a time.
+                f2 S2 = (f2){q2.x, q2.y} * D01;
+                S2 = __builtin_elementwise_fma((f2){q2.z, q2.w}, D2i, S2);
+                g_rg = dc2 * D01;
+                g_bd = dc2 * D2i;
                 if (DIM == 4) {
-                    S = fmaf(q2.z, drep[0], S);
-                    S = fmaf(q2.w, drep[1], S);
-                    S = fmaf(q3.x, drep[2], S);
-                    S = fmaf(q3.y, drep[3], S);
-#pragma unroll
-                    for (int ch = 0; ch < 4; ++ch) g_rep[ch] = dchannel_dcolor * drep[ch];
+                    S2 = __builtin_elementwise_fma((f2){q3.x, q3.y}, E01, S2);
+                    S2 = __builtin_elementwise_fma((f2){q3.z, q3.w}, E23, S2);
+                    g_r01 = dc2 * E01;
+                    g_r23 = dc2 * E23;
                 }
-                if (INVD) {
-                    S = fmaf(q2.y, dinvd, S);
-                    g_id = dchannel_dcolor * dinvd;
-                }
+                const float S = S2.x + S2.y;
                 accum_S = fmaf(last_alpha, last_S - accum_S, accum_S);
                 last_S = S;
                 float dL_dalpha = S - accum_S;
@@ -190,9 +189,8 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
             // 16 gradient components x 64 pixels -> 16 sums: transpose-reduce inside each
             // row of 16 lanes, fold the four rows with two lane swaps, then 16 lanes add
             // to 16 different LDS words (the four waves of the tile meet there).
-            const float comp[16] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_c0, g_c1, g_c2, g_id,
-                                    DIM == 4 ? g_rep[0] : 0.f, DIM == 4 ? g_rep[1] : 0.f,
-                                    DIM == 4 ? g_rep[2] : 0.f, DIM == 4 ? g_rep[3] : 0.f, 0.f, 0.f};
+            const float comp[16] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_rg.x, g_rg.y, g_bd.x, g_bd.y,
+                                    g_r01.x, g_r01.y, g_r23.x, g_r23.y, 0.f, 0.f};
             const float tot = rows_sum4(row_transpose_sum16(comp, lane));
             if (lane < 16) atomicAdd(&s_acc[j][lane], tot);
         }
@@ -203,7 +201,7 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
             const int j = (tid >> 4) + 16 * h;
             if (j >= nb) break;
             const float v = s_acc[j][tid & 15];
-            if (v != 0.0f) atomicAdd(a.acc + (size_t)s_id[j] * 16 + (tid & 15), v);
+            if (v != 0.0f) atomicAdd(a.acc + (size_t)__float_as_uint(s_q1[j].w) * 16 + (tid & 15), v);
         }
     }
 }

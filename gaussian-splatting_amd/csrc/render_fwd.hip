@@ -37,14 +37,16 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 template <int DIM, bool INVD>
 __global__ void __launch_bounds__(TILE_PIX) render_fwd_kernel(const RenderFwdArgs a) {
+    // One SplatRec per instance, regrouped: the test of an instance needs the first two
+    // quarters only, the other two feed packed (two-float) multiply-adds as they are.
     __shared__ float4 s_q0[TILE_PIX];  // x, y, conic.x, conic.y
-    __shared__ float4 s_q1[TILE_PIX];  // conic.z, opacity, r, g
-    __shared__ float4 s_q2[TILE_PIX];  // b, 1/depth, rep0, rep1
-    __shared__ float4 s_q3[TILE_PIX];  // rep2, rep3, depth, -
-    __shared__ uint32_t s_id[TILE_PIX];
-    __shared__ float s_tau[TILE_PIX];  // power below which alpha < 1/255 for certain
+    __shared__ float4 s_q1[TILE_PIX];  // conic.z, tau, opacity, Gaussian index (bits)
+    __shared__ float4 s_q2[TILE_PIX];  // r, g, b, 1/depth
+    __shared__ float4 s_q3[TILE_PIX];  // rep0 .. rep3
     __shared__ float s_gsum[4][TILE_PIX];
     __shared__ float s_gcnt[4][TILE_PIX];
     __shared__ int s_wdone[4];
@@ -59,12 +61,10 @@ __global__ void __launch_bounds__(TILE_PIX) render_fwd_kernel(const RenderFwdArg
     const uint2 range = a.ranges[tile];
     const int total = (int)(range.y - range.x);
 
-    bool done = !inside;
+    // Per-lane flags live in wave-uniform 64-bit masks (see lanes_where / lane_in).
+    uint64_t live = lanes_where(inside);  // pixels that still accept contributions
     float T = 1.0f;
-    float C0 = 0.f, C1 = 0.f, C2 = 0.f, invd = 0.f;
-    float Re[DIM > 0 ? DIM : 1];
-#pragma unroll
-    for (int i = 0; i < (DIM > 0 ? DIM : 1); ++i) Re[i] = 0.f;
+    f2 Crg = {0.f, 0.f}, Cbd = {0.f, 0.f}, R01 = {0.f, 0.f}, R23 = {0.f, 0.f};  // (r, g), (b, 1/depth), reps
     uint32_t last = 0;
     int last_g = -1;
 
@@ -77,84 +77,86 @@ __global__ void __launch_bounds__(TILE_PIX) render_fwd_kernel(const RenderFwdArg
         if (tid < nb) {
             const uint32_t id = a.point_list[range.x + base + tid];
             const float4* r4 = reinterpret_cast<const float4*>(a.rec + id);
-            s_id[tid] = id;
-            s_q0[tid] = r4[0];
-            s_q1[tid] = r4[1];
-            s_q2[tid] = r4[2];
-            if (DIM > 2) s_q3[tid] = r4[3];
-            // alpha = opacity * exp(power) >= 1/255  <=>  power >= -log(255 * opacity); the margin covers the
-            // rounding of the fast logarithm and of the exponential by orders of magnitude
-            s_tau[tid] = -__logf(255.0f * s_q1[tid].y) - 0.01f;
+            const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
+            s_q0[tid] = r0;
+            // tau: the power below which alpha = opacity * exp(power) < 1/255 for certain, i.e.
+            // -log(255 * opacity) less a margin that covers the rounding of the fast logarithm and of
+            // the exponential by orders of magnitude.  Never below -87, where gs_expf stops falling:
+            // the exponential of a pair that passes this test needs no clamp.
+            const float tau = fmaxf(-__logf(255.0f * r1.y) - 0.01f, -87.0f);
+            s_q1[tid] = make_float4(r1.x, tau, r1.y, __uint_as_float(id));
+            s_q2[tid] = make_float4(r1.z, r1.w, r2.x, r2.y);
+            if (DIM > 2) {
+                const float4 r3 = r4[3];
+                s_q3[tid] = make_float4(r2.z, r2.w, r3.x, r3.y);
+            }
         }
         __syncthreads();
 
-        bool wave_done = __ballot(!done) == 0;
         // Instances in groups of 16: the transmittance a lane contributes to each instance's
         // statistic waits in a register and one transposing reduction per group sums all 16 over
         // the wave (17 lane exchanges per group instead of 6 per instance).
 #pragma unroll 1
         for (int j0 = 0; j0 < nb; j0 += 16) {
-            if (wave_done) {  // nothing left for this wave: its share of the remaining statistics is zero
+            if (live == 0) {  // nothing left for this wave: its share of the remaining statistics is zero
                 if (lane < 16) s_gsum[w][j0 + lane] = s_gcnt[w][j0 + lane] = 0.f;
                 continue;
             }
             float tv[16];
-            float acc_c = 0.f;
+            uint64_t cnt_lo = 0, cnt_hi = 0;  // byte u: number of pixels of the wave that tested instance j0 + u
 #pragma unroll
             for (int u = 0; u < 16; ++u) tv[u] = 0.f;
-            {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int j = j0 + u;
-                    if (wave_done || j >= nb) continue;
-                    const float4 q0 = s_q0[j];
-                    const float4 q1 = s_q1[j];
-                    const V2 xy = {q0.x, q0.y};
-                    const V4 co = {q0.z, q0.w, q1.x, q1.y};
-                    float dx, dy;
-                    const float power = splat_power(xy, pxf, pyf, co, &dx, &dy);
-                    const bool hit = !done && !(power > 0.0f);
-                    const uint64_t hm = __ballot(hit);
-                    if (hm == 0) continue;
-                    tv[u] = hit ? T : 0.0f;
-                    acc_c = (lane == u) ? (float)__popcll(hm) : acc_c;
-                    if (__ballot(hit && power >= s_tau[j]) == 0) continue;  // no pixel of the wave can pass the alpha test
+            for (int u = 0; u < 16; ++u) {
+                const int j = j0 + u;
+                if (live == 0 || j >= nb) continue;
+                const float4 q0 = s_q0[j];
+                const float4 q1 = s_q1[j];
+                asm volatile("" : : "v"(q1.y), "v"(q1.z), "v"(q1.w));  // one 16-byte LDS read, not three sunk ones
+                const V2 xy = {q0.x, q0.y};
+                const V4 co = {q0.z, q0.w, q1.x, q1.z};
+                float dx, dy;
+                const float power = splat_power(xy, pxf, pyf, co, &dx, &dy);
+                const uint64_t hm = lanes_where(!(power > 0.0f)) & live;  // forward.cu:423-432
+                if (hm == 0) continue;
+                tv[u] = lane_in(hm) ? T : 0.0f;
+                if (u < 8) cnt_lo |= (uint64_t)__popcll(hm) << (8 * u);
+                else cnt_hi |= (uint64_t)__popcll(hm) << (8 * (u - 8));
+                const uint64_t pm = lanes_where(power >= q1.y) & hm;
+                if (pm == 0) continue;  // no pixel of the wave can pass the alpha test
 
-                    const float alpha = fmin_(GS_ALPHA_MAX, co.w * gs_expf(power));
-                    const bool pass = hit && !(alpha < GS_ALPHA_MIN);
-                    const float test_T = T * (1 - alpha);
-                    const bool term = pass && (test_T < GS_T_MIN);
-                    done = done || term;
-                    const bool blend = pass && !term;
-                    if (__ballot(blend)) {
-                        const float4 q2 = s_q2[j];
-                        if (blend) {
-                            C0 += q1.z * alpha * T;
-                            C1 += q1.w * alpha * T;
-                            C2 += q2.x * alpha * T;
-                            if (INVD) invd += q2.y * alpha * T;
-                            if (DIM == 4) {
-                                const float4 q3 = s_q3[j];
-                                Re[0] += q2.z * alpha * T;
-                                Re[1] += q2.w * alpha * T;
-                                Re[2] += q3.x * alpha * T;
-                                Re[3] += q3.y * alpha * T;
-                            }
-                            T = test_T;
-                            last = (uint32_t)(base + j + 1);
-                            last_g = (int)s_id[j];
-                        }
+                // lanes outside pm compute values nobody reads
+                const float alpha = __builtin_fminf(GS_ALPHA_MAX, co.w * gs_expf_blend(power));
+                const uint64_t am = lanes_where(!(alpha < GS_ALPHA_MIN)) & pm;
+                if (am == 0) continue;
+                const float test_T = T * (1 - alpha);
+                const uint64_t tm = lanes_where(test_T < GS_T_MIN) & am;  // these pixels are finished
+                live &= ~tm;
+                const uint64_t bm = am & ~tm;
+                if (bm == 0) continue;
+                const float4 q2 = s_q2[j];
+                if (lane_in(bm)) {
+                    // forward.cu:454-464: c * alpha * T per channel, two channels per instruction
+                    const f2 a2 = {alpha, alpha}, T2 = {T, T};
+                    Crg += (f2){q2.x, q2.y} * a2 * T2;
+                    Cbd += (f2){q2.z, q2.w} * a2 * T2;
+                    if (DIM == 4) {
+                        const float4 q3 = s_q3[j];
+                        R01 += (f2){q3.x, q3.y} * a2 * T2;
+                        R23 += (f2){q3.z, q3.w} * a2 * T2;
                     }
-                    if (__ballot(!done) == 0) wave_done = true;
+                    T = test_T;
+                    last = (uint32_t)(base + j + 1);
+                    last_g = (int)__float_as_uint(q1.w);
                 }
             }
             const float tot = rows_sum4(row_transpose_sum16(tv, lane));
             if (lane < 16) {
                 s_gsum[w][j0 + lane] = tot;
-                s_gcnt[w][j0 + lane] = acc_c;
+                s_gcnt[w][j0 + lane] = (float)(uint32_t)((((lane & 8) ? cnt_hi : cnt_lo) >> ((lane & 7) * 8)) & 0xffu);
             }
         }
-        if (lane == 0) s_wdone[w] = wave_done ? 1 : 0;
+        if (lane == 0) s_wdone[w] = live == 0 ? 1 : 0;
         __syncthreads();
         // thread t: component (t & 1) of instance (t >> 1) + 128 h
 #pragma unroll
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(TILE_PIX) render_fwd_kernel(const RenderFwdArg
                 const float c = s_gcnt[0][j] + s_gcnt[1][j] + s_gcnt[2][j] + s_gcnt[3][j];
                 if (c > 0.0f) {
                     const float s = s_gsum[0][j] + s_gsum[1][j] + s_gsum[2][j] + s_gsum[3][j];
-                    float* dst = reinterpret_cast<float*>(a.gstat + s_id[j]) + (tid & 1);
+                    float* dst = reinterpret_cast<float*>(a.gstat + __float_as_uint(s_q1[j].w)) + (tid & 1);
                     atomicAdd(dst, (tid & 1) ? c : s);
                 }
             }
@@ -178,14 +180,16 @@ __global__ void __launch_bounds__(TILE_PIX) render_fwd_kernel(const RenderFwdArg
         a.accum_alpha[pid] = T;
         a.n_contrib[pid] = last;
         a.last_contr[pid] = last_g;
-        a.out_color[pid] = C0 + T * a.bg[0];
-        a.out_color[HW + pid] = C1 + T * a.bg[1];
-        a.out_color[2 * HW + pid] = C2 + T * a.bg[2];
+        a.out_color[pid] = Crg.x + T * a.bg[0];
+        a.out_color[HW + pid] = Crg.y + T * a.bg[1];
+        a.out_color[2 * HW + pid] = Cbd.x + T * a.bg[2];
         if (DIM == 4) {
-#pragma unroll
-            for (int ch = 0; ch < 4; ++ch) a.out_reps[ch * HW + pid] = Re[ch];
+            a.out_reps[pid] = R01.x;
+            a.out_reps[HW + pid] = R01.y;
+            a.out_reps[2 * HW + pid] = R23.x;
+            a.out_reps[3 * HW + pid] = R23.y;
         }
-        if (INVD) a.out_invdepth[pid] = invd;
+        if (INVD) a.out_invdepth[pid] = Cbd.y;
     }
 }
 
