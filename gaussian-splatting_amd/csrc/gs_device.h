@@ -119,6 +119,26 @@ __device__ __forceinline__ float row_transpose_sum16(const float (&v)[16], int l
 __device__ __forceinline__ uint64_t lanes_where(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool lane_in(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// m ? v : 0 per lane for a wave-uniform lane mask m.  Written out because the compiler puts
+// such a mask into VCC (s_and_b64 vcc, ...) and selects with the VOP2 form, and a VOP2
+// v_cndmask whose VCC was last written by the scalar unit costs ~20 cycles on gfx950
+// (measured; 4 with the mask in any other SGPR pair).
+__device__ __forceinline__ float select_or_zero(uint64_t m, float v) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
+    return r;
+}
+
+// splat_power() with its two squared terms as one packed multiply each; same operation
+// order per term, hence the same roundings.  xy: centre, pix: pixel, cxz: (conic.x, conic.z).
+__device__ __forceinline__ float splat_power_pk(f2 xy, f2 pix, f2 cxz, float cy, f2* d) {
+    *d = xy - pix;
+    const f2 t = cxz * *d * *d;
+    return -0.5f * (t.x + t.y) - cy * d->x * d->y;
+}
+
 // gs_expf for the blend kernels: no clamps (callers only use the result on lanes whose
 // argument is in [-87, 0]) and the scaling by 2^n as one v_ldexp.  Same roundings as gs_expf
 // on that interval.

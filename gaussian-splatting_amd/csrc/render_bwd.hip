@@ -33,16 +33,19 @@ __device__ __forceinline__ int xcd_remap_b(int b, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-typedef float f2 __attribute__((ext_vector_type(2)));
+// Instances staged per round.  128 rather than 256 keeps the workgroup at 16 KiB of LDS, so the
+// occupancy is set by the registers (6 waves per SIMD) and not by LDS (4); the kernel is bound by
+// the latency of each wave's instruction stream and gains from every extra wave.
+constexpr int BWD_BATCH = 128;
 
 template <int DIM, bool INVD>
 __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArgs a) {
     // same regrouping of the SplatRec as in the forward kernel
-    __shared__ float4 s_q0[TILE_PIX];  // x, y, conic.x, conic.y
-    __shared__ float4 s_q1[TILE_PIX];  // conic.z, tau, opacity, Gaussian index (bits)
-    __shared__ float4 s_q2[TILE_PIX];  // r, g, b, 1/depth
-    __shared__ float4 s_q3[TILE_PIX];  // rep0 .. rep3
-    __shared__ float s_acc[TILE_PIX][16];
+    __shared__ float4 s_q0[BWD_BATCH];  // x, y, conic.x, conic.z
+    __shared__ float4 s_q1[BWD_BATCH];  // conic.y, tau, opacity, Gaussian index (bits)
+    __shared__ float4 s_q2[BWD_BATCH];  // r, g, b, 1/depth
+    __shared__ float4 s_q3[BWD_BATCH];  // rep0 .. rep3
+    __shared__ float s_acc[BWD_BATCH][16];
     __shared__ uint32_t s_max[4];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -51,7 +54,7 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
     const int px = tx * TILE_X + (w & 1) * 8 + (lane & 7);
     const int py = ty * TILE_Y + (w >> 1) * 8 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
-    const float pxf = (float)px, pyf = (float)py;
+    const f2 pix = {(float)px, (float)py};
     const uint2 range = a.ranges[tile];
     const size_t pid = (size_t)py * a.W + px;
     const size_t HW = (size_t)a.H * a.W;
@@ -94,17 +97,17 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
     __syncthreads();
     const int max_last = (int)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
 
-    for (int base = 0; base < max_last; base += TILE_PIX) {
+    for (int base = 0; base < max_last; base += BWD_BATCH) {
         __syncthreads();
-        const int nb = min(TILE_PIX, max_last - base);
+        const int nb = min(BWD_BATCH, max_last - base);
         if (tid < nb) {
             const uint32_t id = a.point_list[range.x + (uint32_t)(max_last - 1 - base - tid)];
             const float4* r4 = reinterpret_cast<const float4*>(a.rec + id);
             const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
-            s_q0[tid] = r0;
+            s_q0[tid] = make_float4(r0.x, r0.y, r0.z, r1.x);
             // tau as in the forward kernel: power below it cannot reach alpha >= 1/255; never below -87
             const float tau = fmaxf(-__logf(255.0f * r1.y) - 0.01f, -87.0f);
-            s_q1[tid] = make_float4(r1.x, tau, r1.y, __uint_as_float(id));
+            s_q1[tid] = make_float4(r0.w, tau, r1.y, __uint_as_float(id));
             s_q2[tid] = make_float4(r1.z, r1.w, r2.x, r2.y);
             if (DIM > 2) {
                 const float4 r3 = r4[3];
@@ -112,8 +115,8 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
             }
         }
         {
-            float4* z = reinterpret_cast<float4*>(&s_acc[tid][0]);
-            z[0] = z[1] = z[2] = z[3] = make_float4(0, 0, 0, 0);
+            float4* z = reinterpret_cast<float4*>(&s_acc[0][0]) + tid;  // 128 x 16 floats = 512 float4
+            z[0] = z[TILE_PIX] = make_float4(0, 0, 0, 0);
         }
         __syncthreads();
 
@@ -123,10 +126,10 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
             const float4 q0 = s_q0[j];
             const float4 q1 = s_q1[j];
             asm volatile("" : : "v"(q1.y), "v"(q1.z));  // one 16-byte LDS read
-            const V2 xy = {q0.x, q0.y};
-            const V4 co = {q0.z, q0.w, q1.x, q1.z};
-            float dx, dy;
-            const float power = splat_power(xy, pxf, pyf, co, &dx, &dy);
+            f2 d;
+            const float power = splat_power_pk((f2){q0.x, q0.y}, pix, (f2){q0.z, q0.w}, q1.x, &d);
+            const float dx = d.x, dy = d.y;
+            const V4 co = {q0.z, q1.x, q0.w, q1.z};  // conic.x, .y, .z, opacity
             // backward.cu:592-611 as lane masks; pixels outside the image have last_contributor 0
             const uint64_t hm = lanes_where(contributor < last_contributor) & lanes_where(!(power > 0.0f));
             const uint64_t pm = lanes_where(power >= q1.y) & hm;
@@ -197,7 +200,7 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
         __syncthreads();
         // 16 lanes per instance: one 64-byte GradRec update
 #pragma unroll 1
-        for (int h = 0; h < 16; ++h) {
+        for (int h = 0; h < BWD_BATCH / 16; ++h) {
             const int j = (tid >> 4) + 16 * h;
             if (j >= nb) break;
             const float v = s_acc[j][tid & 15];

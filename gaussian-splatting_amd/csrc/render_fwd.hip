@@ -37,14 +37,12 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-
 template <int DIM, bool INVD>
-__global__ void __launch_bounds__(TILE_PIX) render_fwd_kernel(const RenderFwdArgs a) {
+__global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6, 6))) render_fwd_kernel(const RenderFwdArgs a) {
     // One SplatRec per instance, regrouped: the test of an instance needs the first two
     // quarters only, the other two feed packed (two-float) multiply-adds as they are.
-    __shared__ float4 s_q0[TILE_PIX];  // x, y, conic.x, conic.y
-    __shared__ float4 s_q1[TILE_PIX];  // conic.z, tau, opacity, Gaussian index (bits)
+    __shared__ float4 s_q0[TILE_PIX];  // x, y, conic.x, conic.z
+    __shared__ float4 s_q1[TILE_PIX];  // conic.y, tau, opacity, Gaussian index (bits)
     __shared__ float4 s_q2[TILE_PIX];  // r, g, b, 1/depth
     __shared__ float4 s_q3[TILE_PIX];  // rep0 .. rep3
     __shared__ float s_gsum[4][TILE_PIX];
@@ -57,7 +55,7 @@ __global__ void __launch_bounds__(TILE_PIX) render_fwd_kernel(const RenderFwdArg
     const int px = tx * TILE_X + (w & 1) * 8 + (lane & 7);
     const int py = ty * TILE_Y + (w >> 1) * 8 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
-    const float pxf = (float)px, pyf = (float)py;
+    const f2 pix = {(float)px, (float)py};
     const uint2 range = a.ranges[tile];
     const int total = (int)(range.y - range.x);
 
@@ -78,18 +76,22 @@ __global__ void __launch_bounds__(TILE_PIX) render_fwd_kernel(const RenderFwdArg
             const uint32_t id = a.point_list[range.x + base + tid];
             const float4* r4 = reinterpret_cast<const float4*>(a.rec + id);
             const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
-            s_q0[tid] = r0;
+            s_q0[tid] = make_float4(r0.x, r0.y, r0.z, r1.x);
             // tau: the power below which alpha = opacity * exp(power) < 1/255 for certain, i.e.
             // -log(255 * opacity) less a margin that covers the rounding of the fast logarithm and of
             // the exponential by orders of magnitude.  Never below -87, where gs_expf stops falling:
             // the exponential of a pair that passes this test needs no clamp.
             const float tau = fmaxf(-__logf(255.0f * r1.y) - 0.01f, -87.0f);
-            s_q1[tid] = make_float4(r1.x, tau, r1.y, __uint_as_float(id));
+            s_q1[tid] = make_float4(r0.w, tau, r1.y, __uint_as_float(id));
             s_q2[tid] = make_float4(r1.z, r1.w, r2.x, r2.y);
             if (DIM > 2) {
                 const float4 r3 = r4[3];
                 s_q3[tid] = make_float4(r2.z, r2.w, r3.x, r3.y);
             }
+        } else if (tid < ((nb + 15) & ~15)) {
+            // the last group of 16 is filled up with entries whose power is positive everywhere
+            s_q0[tid] = make_float4(-1e4f, -1e4f, -1.f, -1.f);
+            s_q1[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
 
@@ -109,24 +111,22 @@ __global__ void __launch_bounds__(TILE_PIX) render_fwd_kernel(const RenderFwdArg
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int j = j0 + u;
-                if (live == 0 || j >= nb) continue;
                 const float4 q0 = s_q0[j];
                 const float4 q1 = s_q1[j];
                 asm volatile("" : : "v"(q1.y), "v"(q1.z), "v"(q1.w));  // one 16-byte LDS read, not three sunk ones
-                const V2 xy = {q0.x, q0.y};
-                const V4 co = {q0.z, q0.w, q1.x, q1.z};
-                float dx, dy;
-                const float power = splat_power(xy, pxf, pyf, co, &dx, &dy);
-                const uint64_t hm = lanes_where(!(power > 0.0f)) & live;  // forward.cu:423-432
-                if (hm == 0) continue;
-                tv[u] = lane_in(hm) ? T : 0.0f;
+                f2 d;
+                const float power = splat_power_pk((f2){q0.x, q0.y}, pix, (f2){q0.z, q0.w}, q1.x, &d);
+                // forward.cu:423-432: the statistics count every pixel that reaches this instance with a
+                // non-positive power, whatever its alpha
+                const uint64_t hm = lanes_where(!(power > 0.0f)) & live;
+                tv[u] = select_or_zero(hm, T);
                 if (u < 8) cnt_lo |= (uint64_t)__popcll(hm) << (8 * u);
                 else cnt_hi |= (uint64_t)__popcll(hm) << (8 * (u - 8));
                 const uint64_t pm = lanes_where(power >= q1.y) & hm;
                 if (pm == 0) continue;  // no pixel of the wave can pass the alpha test
 
                 // lanes outside pm compute values nobody reads
-                const float alpha = __builtin_fminf(GS_ALPHA_MAX, co.w * gs_expf_blend(power));
+                const float alpha = __builtin_fminf(GS_ALPHA_MAX, q1.z * gs_expf_blend(power));
                 const uint64_t am = lanes_where(!(alpha < GS_ALPHA_MIN)) & pm;
                 if (am == 0) continue;
                 const float test_T = T * (1 - alpha);

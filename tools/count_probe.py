@@ -1,10 +1,12 @@
-"""Reads the debug counters of an instrumented build (GSPLAT_AMD_LIB=tools/lib_count.so):
-per-wave instance visits / threshold passes of the two blend kernels and the spread of
-workgroup durations, on the bench workload.  Development tool, not part of the product."""
+"""Per-workgroup start / end timestamps of the two blend kernels from an instrumented build
+(GSPLAT_AMD_LIB=tools/lib_wgt.so, see the patch step in the development notes): how many
+workgroups run concurrently over the kernel's life, how long the tail is, how the duration
+relates to the entries a tile walks.  Development tool, not part of the product."""
 import ctypes as C
 import os
 import sys
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,27 +25,32 @@ rs = bench.make_settings(synth.street_camera(W, H, 0, 8), dev, sc["sh_degree"])
 gt = torch.rand((3, H, W), device=dev)
 sink = ParamGradSink(*params.values(), defer=True)
 L = G.lib()
-buf = (C.c_ulonglong * 16)()
-
-
-def read(fn, reset=1):
-    getattr(L, fn)(buf, reset)
-    return list(buf)
-
+NT = ((W + 15) // 16) * ((H + 15) // 16)
 
 for it in range(3):
-    read("gsr_dbg_fwd"), read("gsr_dbg_bwd")
     sink.begin_step()
     out = bench.render_params(params, rs, sink)
     bench.train_loss(out, gt).backward()
     sink.flush()
     torch.cuda.synchronize()
-f, b = read("gsr_dbg_fwd"), read("gsr_dbg_bwd")
-print("fwd: wave-instances visited %d, hit %d, pass tau %d, blend %d, rounds %d" % (f[0], f[1], f[2], f[3], f[8]))
-print("fwd: workgroups %d, list entries total %d; duration sum %.1f us, mean %.2f us, max %.2f us, kernel span %.1f us"
-      % (f[9], f[10], f[4] / 100, f[4] / 100 / max(1, f[9]), f[5] / 100, (f[7] - f[6]) / 100))
-print("fwd: mean concurrency %.1f workgroups" % (f[4] / max(1, f[7] - f[6])))
-print("bwd: wave-instances visited %d, pass tau %d, valid %d" % (b[0], b[2], b[3]))
-print("bwd: workgroups %d, walked entries total %d; duration sum %.1f us, mean %.2f us, max %.2f us, kernel span %.1f us"
-      % (b[9], b[10], b[4] / 100, b[4] / 100 / max(1, b[9]), b[5] / 100, (b[7] - b[6]) / 100))
-print("bwd: mean concurrency %.1f workgroups" % (b[4] / max(1, b[7] - b[6])))
+
+for tag in ("f", "b"):
+    buf = (C.c_ulonglong * (4 * NT))()
+    rc = getattr(L, "gsr_dbg_wgt_" + tag)(buf, NT)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(NT, 4).astype(np.int64)
+    t0, t1, n = a[:, 0], a[:, 1], a[:, 2]
+    base = t0.min()
+    t0, t1 = (t0 - base) / 100.0, (t1 - base) / 100.0   # microseconds (100 MHz counter)
+    dur = t1 - t0
+    span = t1.max()
+    print(f"== {tag}: rc {rc}, workgroups {NT}, span {span:.1f} us, duration mean {dur.mean():.1f} median {np.median(dur):.1f} "
+          f"p90 {np.percentile(dur, 90):.1f} p99 {np.percentile(dur, 99):.1f} max {dur.max():.1f} us; "
+          f"sum {dur.sum():.0f} us -> mean concurrency {dur.sum() / span:.0f}")
+    # concurrency timeline in 20 slices
+    edges = np.linspace(0, span, 21)
+    conc = [(np.minimum(t1, e1) - np.maximum(t0, e0)).clip(min=0).sum() / (e1 - e0) for e0, e1 in zip(edges[:-1], edges[1:])]
+    print("   concurrency per 5% slice:", " ".join(f"{c:.0f}" for c in conc))
+    print(f"   last start at {t0.max():.1f} us; entries walked: mean {n.mean():.0f} max {n.max()}; "
+          f"corr(duration, entries) {np.corrcoef(dur, n)[0, 1]:.2f}; us per entry (sum/sum) {dur.sum() / max(1, n.sum()):.3f}")
+    order = np.argsort(-dur)[:5]
+    print("   longest:", [(int(i), round(float(dur[i]), 1), int(n[i]), round(float(t0[i]), 1)) for i in order])
