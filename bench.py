@@ -105,7 +105,9 @@ class KernelTimer:
 
     PAIRS = {"preprocess": (0, 1), "scan": (1, 2), "host_sync_gap": (2, 3), "depth_order": (3, 4), "emit_keys": (4, 5), "sort": (5, 6),
              "tile_ranges": (6, 7), "render_fwd": (7, 8), "finish_stats": (8, 9), "bwd_clear": (10, 11),
-             "render_bwd": (11, 12), "preprocess_bwd": (12, 13), "preprocess_bwd_batch": (14, 15)}
+             "render_bwd": (11, 12), "preprocess_bwd": (12, 13), "preprocess_bwd_batch": (14, 15),
+             "preprocess_batch": (16, 17)}
+    PER_STEP = ("preprocess_bwd_batch", "preprocess_batch")   # one launch per step, recorded in one event set of it
 
     def __init__(self, sets):
         import _gsplat_lib as G
@@ -121,17 +123,19 @@ class KernelTimer:
     def arm(self, i):
         self.G.set_profile_events(self.arrays[i] if i is not None else None)
 
-    def means_ms(self, fwd_only=False, batch_sets=None):
-        """batch_sets: indices of the event sets that were armed when a batched backward ran."""
+    def means_ms(self, fwd_only=False, batch_sets=None, fwd_batch_sets=None):
+        """batch_sets / fwd_batch_sets: indices of the event sets that were armed when the batched
+        backward / the batched forward preprocess ran."""
         out = {}
         for k, (a, b) in self.PAIRS.items():
-            if fwd_only and a >= 10:
+            if fwd_only and 10 <= a < 16:
                 continue
             rows = self.events
-            if a >= 14:
-                if not batch_sets:
+            if k in self.PER_STEP:
+                sets = batch_sets if k == "preprocess_bwd_batch" else fwd_batch_sets
+                if not sets:
                     continue
-                rows = [self.events[i] for i in batch_sets]
+                rows = [self.events[i] for i in sets]
             out[k] = float(np.mean([row[a].elapsed_time(row[b]) for row in rows]))
         return out
 
@@ -152,12 +156,13 @@ def algorithmic_bytes(kernel, P, visible, R, HW, passes):
         "render_bwd": 60.0 * R + 40.0 * HW + 56.0 * R,
         "preprocess_bwd": 575.0 * visible,
         "preprocess_bwd_batch": 575.0 * visible,   # per view of the batch; bench scales it by the views per launch
+        "preprocess_batch": 315.0 * visible + 20.0 * (P - visible),   # likewise
     }.get(kernel)
 
 
 # What bounds each kernel (the blend kernels stop early per pixel and are limited by
 # VALU / LDS issue, not by the bytes they move; the others stream through HBM).
-BOUND = {"preprocess_bwd_batch": "hbm", "preprocess": "hbm", "depth_order": "hbm", "emit_keys": "hbm", "sort": "hbm", "tile_ranges": "hbm",
+BOUND = {"preprocess_bwd_batch": "hbm", "preprocess_batch": "hbm", "preprocess": "hbm", "depth_order": "hbm", "emit_keys": "hbm", "sort": "hbm", "tile_ranges": "hbm",
          "render_fwd": "valu+lds", "render_bwd": "valu+lds+atomics", "preprocess_bwd": "hbm"}
 
 
@@ -207,6 +212,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--api", choices=("params", "reference"), default="params",
                     help="params: forward_params (raw parameters); reference: unchanged reference signature")
+    ap.add_argument("--no-batch-forward", action="store_true",
+                    help="run the forward preprocess per view instead of once per step for all its views")
     ap.add_argument("--no-defer", action="store_true",
                     help="run the per-Gaussian backward after every view instead of once per step for all its views")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -256,12 +263,13 @@ def main():
     def one_view(rs, gt):
         if args.fwd_only:
             with torch.no_grad():
-                return render_params(params, rs) if use_params else render_reference_api(params, rs)
+                return render_params(params, rs, sink) if use_params else render_reference_api(params, rs)
         out = render_params(params, rs, sink) if use_params else render_reference_api(params, rs)
         train_loss(out, gt).backward()
         return out
 
     reducer_ms = []
+    batch_fwd = use_params and not args.no_batch_forward and V > 1
 
     def step(k=None, timer=None):
         if use_params:
@@ -270,6 +278,10 @@ def main():
             for p in leaves:
                 p.grad = None
         out = None
+        if batch_fwd:
+            if timer is not None:
+                timer.arm(k * V)
+            sink.prepare_views([rs for rs, _ in views])   # the forward preprocess of all V views, once
         for v, (rs, gt) in enumerate(views):
             if timer is not None:
                 timer.arm(k * V + v)
@@ -315,7 +327,10 @@ def main():
         dt = float(tmax.item())
 
     deferred = use_params and sink.defer and not args.fwd_only
-    kernels = timer.means_ms(args.fwd_only, [k * V + V - 1 for k in range(args.steps)] if deferred else None)
+    kernels = timer.means_ms(args.fwd_only, [k * V + V - 1 for k in range(args.steps)] if deferred else None,
+                             [k * V for k in range(args.steps)] if batch_fwd else None)
+    if batch_fwd:
+        kernels.pop("preprocess")   # that slot is empty when the views were preprocessed together
     if deferred:
         kernels["means2d_grad"] = kernels.pop("preprocess_bwd")   # in deferred mode that slot times the gradient copy
     gx, gy = (W + 15) // 16, (H + 15) // 16
@@ -410,8 +425,8 @@ def main():
     if rank == 0:
         traffic = load_pmc_traffic(P, W, H)
         per_kernel = {}
-        launches = lambda k: 1 if k == "preprocess_bwd_batch" else V          # per step
-        units = lambda k: V if k == "preprocess_bwd_batch" else 1             # views one launch works for
+        launches = lambda k: 1 if k in KernelTimer.PER_STEP else V          # per step
+        units = lambda k: V if k in KernelTimer.PER_STEP else 1             # views one launch works for
 
         def alg(k):
             ab = algorithmic_bytes(k, P, visible, R, H * W, passes)

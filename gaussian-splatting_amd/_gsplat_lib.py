@@ -29,7 +29,7 @@ class GsrForwardOut(C.Structure):
     _fields_ = [(n, _vp) for n in ("out_color", "out_invdepth", "radii", "accum_alpha", "gauss_sum", "gauss_count",
                                    "last_contr_gauss", "out_depths", "out_reps")] + \
                [("geom_buffer", _vp), ("geom_bytes", C.c_size_t), ("image_buffer", _vp), ("image_bytes", C.c_size_t),
-                ("num_visible", C.c_int64)]
+                ("num_visible", C.c_int64), ("preprocessed", C.c_int)]
 
 
 class GsrBackwardIO(C.Structure):
@@ -43,6 +43,12 @@ class GsrBackwardView(C.Structure):
     _fields_ = [("viewmatrix", _vp), ("projmatrix", _vp), ("campos", _vp), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
                 ("W", C.c_int), ("H", C.c_int), ("antialiasing", C.c_int), ("has_invdepth", C.c_int), ("radii", _vp),
                 ("geom_buffer", _vp), ("work", _vp), ("dL_dmeans2D", _vp)]
+
+
+class GsrForwardView(C.Structure):
+    _fields_ = [("viewmatrix", _vp), ("projmatrix", _vp), ("campos", _vp), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("W", C.c_int), ("H", C.c_int), ("antialiasing", C.c_int), ("radii", _vp), ("out_depths", _vp),
+                ("geom_buffer", _vp), ("geom_bytes", C.c_size_t)]
 
 
 class GsrLayout(C.Structure):
@@ -85,6 +91,8 @@ def lib():
     L.gsr_backward_geometry_batch.restype = C.c_int
     L.gsr_backward_geometry_batch.argtypes = [C.POINTER(GsrScene), C.c_int, C.POINTER(GsrBackwardView),
                                               C.POINTER(GsrBackwardIO), _vp]
+    L.gsr_preprocess_batch.restype = C.c_int
+    L.gsr_preprocess_batch.argtypes = [C.POINTER(GsrScene), C.c_int, C.POINTER(GsrForwardView), _vp]
     L.gsr_mark_visible.restype = C.c_int
     L.gsr_mark_visible.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _vp]
     L.gsr_sort_pairs_u64_u32.restype = C.c_int
@@ -114,14 +122,15 @@ def lib():
 
 EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backward_work_bytes",
             "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_backward_blend",
-            "gsr_backward_geometry_batch", "gsr_mark_visible", "gsr_sort_temp_bytes",
+            "gsr_backward_geometry_batch", "gsr_preprocess_batch", "gsr_mark_visible", "gsr_sort_temp_bytes",
             "gsr_sort_pairs_u64_u32", "gsr_layout", "gsr_sorted_keys_u64", "gsk_dist2_temp_bytes", "gsk_dist2", "gss_ssim_forward",
             "gss_ssim_backward", "gso_adam_update", "gso_densify_stats", "gsr_status_string")
 
 
-NUM_PROFILE_EVENTS = 16
+NUM_PROFILE_EVENTS = 18
 EVENT_NAMES = ("stage1_begin", "preprocess", "scan", "stage2_begin", "depth_order", "emit", "sort", "ranges", "render",
-               "finish", "bwd_begin", "bwd_clear", "bwd_render", "bwd_preprocess", "batch_begin", "batch")
+               "finish", "bwd_begin", "bwd_clear", "bwd_render", "bwd_preprocess", "batch_begin", "batch",
+               "fwd_batch_begin", "fwd_batch")
 
 # Optional per-thread hook used by bench.py: a ctypes array of hipEvent_t handles
 # that the next rasterizer calls record around their kernels.

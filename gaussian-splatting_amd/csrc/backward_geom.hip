@@ -35,7 +35,7 @@ struct PreBwdArgs {
     const float* opacities;
     const float* scales;
     const float* rotations;
-    const float* cov3D;  // supplied or the one the forward computed
+    const float* cov3D;  // the precomputed 3D covariance, if that is what the caller gave
     CamPtrs cam;
     const int* radii;
     const uint8_t* clamped;
@@ -55,8 +55,6 @@ struct PreBwdArgs {
 
 enum ShMode { SH_NONE = 0, SH_DIRECT = 1, SH_CAT16 = 2, SH_SPLIT16 = 3 };
 
-constexpr int REST_ROW_F = 45;              // dwords per row of the [P,15,3] tensor
-constexpr int REST_WAVE_F = 64 * REST_ROW_F;  // 2880 dwords = 11520 bytes per wave
 
 template <int MODE>
 struct ShLds {
@@ -150,9 +148,25 @@ __device__ __forceinline__ void pre_bwd_rendered(const PreBwdArgs& a, size_t i, 
     }
     if (MODE == SH_CAT16 || MODE == SH_SPLIT16) wave_lds_sync();
 
+    // The 3D covariance: given, or recomputed from scale and rotation (the same arithmetic as the
+    // forward, identical values; a forward that went through gsr_preprocess_batch does not store it).
     float cov6[6];
+    V3 sc = v3(1, 1, 1);
+    V4 q = {1, 0, 0, 0};
+    float dn = 1.0f;
+    if (a.scales) {
+        sc = v3(a.scales[3 * i], a.scales[3 * i + 1], a.scales[3 * i + 2]);
+        const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[i];
+        q = {q4.x, q4.y, q4.z, q4.w};
+        if (a.raw) {
+            sc = act_exp3(sc);
+            q = act_normalize4(q, &dn);
+        }
+        cov3d_from_scale_rot(sc, c.scale_modifier, q, cov6);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) cov6[k] = a.cov3D[6 * i + k];
+        for (int k = 0; k < 6; ++k) cov6[k] = a.cov3D[6 * i + k];
+    }
     float opac = a.opacities[i];
     if (a.raw) opac = act_sigmoid(opac);
     float dop = g1.y;
@@ -164,14 +178,6 @@ __device__ __forceinline__ void pre_bwd_rendered(const PreBwdArgs& a, size_t i, 
     if (a.raw) dop = act_sigmoid_bwd(opac, dop);
 
     if (a.scales) {
-        V3 sc = v3(a.scales[3 * i], a.scales[3 * i + 1], a.scales[3 * i + 2]);
-        const float4 q4 = reinterpret_cast<const float4*>(a.rotations)[i];
-        V4 q = {q4.x, q4.y, q4.z, q4.w};
-        float dn = 1.0f;
-        if (a.raw) {
-            sc = act_exp3(sc);
-            q = act_normalize4(q, &dn);
-        }
         V3 ds;
         V4 dq;
         cov3d_from_scale_rot_bwd(sc, c.scale_modifier, q, dcov6, &ds, &dq);
@@ -261,42 +267,6 @@ __device__ __forceinline__ void pre_bwd_unrendered(const PreBwdArgs& a, size_t i
         reinterpret_cast<float4*>(a.dL_drotations)[i] = make_float4(0, 0, 0, 0);
     }
     if (a.DIM == 4) reinterpret_cast<float4*>(a.dL_dreps)[i] = make_float4(0, 0, 0, 0);
-}
-
-// The wave's block of the [P,15,3] tensor (nrows x 45 dwords, contiguous, 16-byte
-// aligned because a wave starts at a multiple of 64 rows) between global memory
-// and its linear LDS image, 16 bytes per lane and step.  A chunk can straddle
-// two rows; it moves if either row's bit is set in `rows`.
-// OP 0: LDS = global, 1: global = LDS, 2: global += LDS.
-template <int OP>
-__device__ __forceinline__ void rest_rows_copy(float* __restrict__ g, float* lds, uint64_t rows, int nrows, int lane) {
-    const int total = nrows * REST_ROW_F;
-    float4* g4 = reinterpret_cast<float4*>(g);
-    float4* l4 = reinterpret_cast<float4*>(lds);
-#pragma unroll
-    for (int it = 0; it < (REST_WAVE_F / 4 + 63) / 64; ++it) {
-        const int i = it * 64 + lane;
-        if (4 * i + 3 < total) {
-            const int r0 = (4 * i) / REST_ROW_F, r1 = (4 * i + 3) / REST_ROW_F;
-            if (((rows >> r0) | (rows >> r1)) & 1ull) {
-                if (OP == 0) {
-                    l4[i] = g4[i];
-                } else if (OP == 1) {
-                    g4[i] = l4[i];
-                } else {
-                    const float4 o = g4[i], v = l4[i];
-                    g4[i] = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
-                }
-            }
-        }
-    }
-    // up to three dwords left when the last wave is partial
-    const int f = (total & ~3) + lane;
-    if (lane < 3 && f < total && ((rows >> (f / REST_ROW_F)) & 1ull)) {
-        if (OP == 0) lds[f] = g[f];
-        else if (OP == 1) g[f] = lds[f];
-        else g[f] += lds[f];
-    }
 }
 
 #ifndef PRE_BWD_WAVES
@@ -601,7 +571,7 @@ hipError_t launch_preprocess_bwd(const GsrScene& s, const int* radii, const Geom
     a.raw = s.raw_params; a.accumulate = io.accumulate;
     a.means3D = s.means3D; a.shs = s.shs; a.shs_rest = s.shs_rest; a.colors_precomp = s.colors_precomp;
     a.opacities = s.opacities; a.scales = s.scales; a.rotations = s.rotations;
-    a.cov3D = s.cov3D_precomp ? s.cov3D_precomp : g.cov3D;
+    a.cov3D = s.cov3D_precomp;  // null: recomputed from scales and rotations
     a.cam.view = s.viewmatrix; a.cam.proj = s.projmatrix; a.cam.campos = s.campos;
     a.radii = radii; a.clamped = g.clamped; a.acc = acc;
     a.has_invdepth = io.dL_dout_invdepth != nullptr;

@@ -69,7 +69,7 @@ int gsr_forward_stage1(const GsrScene* s, GsrForwardOut* o, void* stream, int64_
     const bool debug = s->debug != 0;
     const GeomBuf g = geom_buf(o->geom_buffer, (size_t)s->P);
     mark(s, GSR_EV_STAGE1_BEGIN, st);
-    GSR_TRY(launch_preprocess_fwd(*s, *o, g, st));
+    if (!o->preprocessed) GSR_TRY(launch_preprocess_fwd(*s, *o, g, st));
     mark(s, GSR_EV_PREPROCESS, st);
     GSR_TRY(launch_scan_blocks(g, (s->P + PRE_BLOCK - 1) / PRE_BLOCK, st));
     mark(s, GSR_EV_SCAN, st);
@@ -226,6 +226,29 @@ int gsr_backward_geometry_batch(const GsrScene* s, int nviews, const GsrBackward
     mark(s, GSR_EV_BATCH_BEGIN, st);
     GSR_TRY(launch_preprocess_bwd_batch(*s, nviews, views, *io, st));
     mark(s, GSR_EV_BATCH, st);
+    return GSR_OK;
+}
+
+int gsr_preprocess_batch(const GsrScene* s, int nviews, const GsrForwardView* views, void* stream) {
+    if (!s || nviews < 0 || (nviews > 0 && !views)) return GSR_ERR_ARG;
+    if (s->P < 0) return GSR_ERR_ARG;
+    if (s->DIM != 0 && s->DIM != 4) return GSR_ERR_DIM;
+    if (s->P == 0 || nviews == 0) return GSR_OK;
+    if (!s->means3D || !s->opacities || !s->scales || !s->rotations || !s->shs || !s->shs_rest) return GSR_ERR_ARG;
+    if (s->M != 16 || s->D < 0 || s->D > 3 || s->cov3D_precomp || s->colors_precomp) return GSR_ERR_ARG;
+    if (s->DIM > 0 && !s->reps) return GSR_ERR_ARG;
+    for (int v = 0; v < nviews; ++v) {
+        const GsrForwardView& fv = views[v];
+        if (!fv.viewmatrix || !fv.projmatrix || !fv.campos || !fv.radii || !fv.out_depths || !fv.geom_buffer ||
+            fv.W <= 0 || fv.H <= 0 || fv.W > 65535 * TILE_X || fv.H > 65535 * TILE_Y)
+            return GSR_ERR_ARG;
+        if (fv.geom_bytes < gsr_geom_bytes(s->P)) return GSR_ERR_BUFFER;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const bool debug = s->debug != 0;
+    mark(s, GSR_EV_FWD_BATCH_BEGIN, st);
+    GSR_TRY(launch_preprocess_fwd_batch(*s, nviews, views, st));
+    mark(s, GSR_EV_FWD_BATCH, st);
     return GSR_OK;
 }
 

@@ -121,6 +121,160 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs
     }
 }
 
+// ------------------------------------------------------------------ several views at once
+// The forward preprocess of a batch of views in one pass (no counterpart in the
+// reference, which renders one view per iteration): each Gaussian's parameters
+// and SH row are read once for all the views of an optimiser step instead of
+// once per view; per view only the results are written.  The same functions in
+// the same order as preprocess_fwd_kernel: every per-view array comes out bit
+// for bit as from the one-view kernel.  Two sweeps over the views: the first
+// projects the Gaussian into every view and writes the small per-Gaussian
+// arrays (radius, tile rectangle, depth), which tells whether any view renders
+// it and hence whether its SH row has to be fetched; the second repeats the
+// projection for the views that do (arithmetic is cheap here, the kernel waits
+// on memory) and writes each 64-byte SplatRec whole, colour included: filling
+// the colour into records written in the first sweep cost a partial-line
+// write per record and view.
+// Needs [P,1,3] + [P,15,3] SH tensors and scales + rotations; the 3D covariance
+// is not stored (the backward recomputes it from scale and rotation).
+constexpr int MAX_FWD_BATCH_VIEWS = 8;
+
+struct FwdBatchView {
+    CamPtrs cam;
+    float tanx, tany;
+    int W, H, aa;
+    int* radii;
+    float* out_depths;
+    SplatRec* rec;
+    uint4* bin;
+    float2* gstat;
+    uint8_t* clamped;
+    uint32_t* block_sums;
+    uint32_t* vis_sums;
+};
+
+struct PreBatchArgs {
+    int P, D, M, DIM;
+    float mod;
+    int raw;
+    const float* means3D;
+    const float* shs;
+    const float* shs_rest;
+    const float* opacities;
+    const float* scales;
+    const float* rotations;
+    const float* reps;
+    int nviews;
+    FwdBatchView v[MAX_FWD_BATCH_VIEWS];
+};
+
+__global__ void __launch_bounds__(PRE_BLOCK, 2) preprocess_fwd_batch_kernel(const PreBatchArgs b) {
+    __shared__ __align__(16) char s_sh[4 * REST_WAVE_F * 4];
+    __shared__ uint32_t s_tiles[MAX_FWD_BATCH_VIEWS][4];
+    __shared__ uint32_t s_vis[MAX_FWD_BATCH_VIEWS][4];
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wave_g0 = blockIdx.x * PRE_BLOCK + w * 64;
+    const int nrows = min(64, b.P - wave_g0);  // <= 0 for waves past the end
+    const bool live = idx < b.P;
+    const size_t i = (size_t)(live ? idx : 0);
+    float* lds = reinterpret_cast<float*>(s_sh) + w * REST_WAVE_F;
+
+    const V3 p = v3(b.means3D[3 * i], b.means3D[3 * i + 1], b.means3D[3 * i + 2]);
+    float cov6[6];
+    float opac = b.opacities[i];
+    {
+        V3 sc = v3(b.scales[3 * i], b.scales[3 * i + 1], b.scales[3 * i + 2]);
+        const float4 q4 = reinterpret_cast<const float4*>(b.rotations)[i];
+        V4 q = {q4.x, q4.y, q4.z, q4.w};
+        if (b.raw) {
+            float dn;
+            sc = act_exp3(sc);
+            q = act_normalize4(q, &dn);
+            opac = act_sigmoid(opac);
+        }
+        cov3d_from_scale_rot(sc, b.mod, q, cov6);
+    }
+
+    // First sweep: which views render this Gaussian, and the small per-Gaussian arrays.
+    uint32_t seen = 0;  // bit v: view v renders it
+#pragma unroll 1
+    for (int v = 0; v < b.nviews; ++v) {
+        const FwdBatchView& bv = b.v[v];
+        uint32_t tiles = 0;
+        if (live) {
+            const Cam c = load_cam(bv.cam, bv.W, bv.H, bv.tanx, bv.tany, b.mod, b.D, b.M, bv.aa);
+            int radius = 0;
+            uint4 bin = make_uint4(0, 0, 0, 0);
+            float depth;
+            if (!near_cull(p, c.view, &depth)) {
+                Splat sp;
+                if (project_splat(c, p, cov6, opac, depth, &sp)) {
+                    bv.out_depths[i] = sp.depth;
+                    radius = sp.radius;
+                    tiles = sp.tiles;
+                    bin.x = (uint32_t)sp.rect.x0 | ((uint32_t)sp.rect.y0 << 16);
+                    bin.y = (uint32_t)(sp.rect.x1 - sp.rect.x0) | ((uint32_t)(sp.rect.y1 - sp.rect.y0) << 16);
+                    bin.z = f2bits(sp.depth);
+                    bin.w = tiles;
+                    seen |= 1u << v;
+                }
+            }
+            bv.radii[i] = radius;
+            bv.bin[i] = bin;
+            bv.gstat[i] = make_float2(0.0f, 0.0f);
+        }
+        const uint32_t ws = wave_sum_u32(tiles);
+        const uint32_t wv = (uint32_t)__popcll(__ballot(tiles > 0));
+        if (lane == 0) {
+            s_tiles[v][w] = ws;
+            s_vis[v][w] = wv;
+        }
+    }
+
+    // Second sweep: the SplatRec of every view that renders it, colour included.
+    const uint64_t rows = __ballot(seen != 0);
+    if (rows && nrows > 0)
+        rest_rows_copy<0>(const_cast<float*>(b.shs_rest) + (size_t)wave_g0 * REST_ROW_F, lds, rows, nrows, lane);
+    wave_lds_sync();
+    if (seen) {
+        float shv[SH_ROW_F];
+        shv[0] = b.shs[3 * i];
+        shv[1] = b.shs[3 * i + 1];
+        shv[2] = b.shs[3 * i + 2];
+        const float* row = lds + lane * REST_ROW_F;
+#pragma unroll
+        for (int k = 0; k < REST_ROW_F; ++k) shv[3 + k] = row[k];
+        const ShRegs sh = {shv};
+        float4 rp = make_float4(0, 0, 0, 0);
+        if (b.DIM == 4) rp = reinterpret_cast<const float4*>(b.reps)[i];
+#pragma unroll 1
+        for (int v = 0; v < b.nviews; ++v) {
+            if (!((seen >> v) & 1u)) continue;
+            const FwdBatchView& bv = b.v[v];
+            const Cam c = load_cam(bv.cam, bv.W, bv.H, bv.tanx, bv.tany, b.mod, b.D, b.M, bv.aa);
+            float depth;
+            Splat sp;
+            near_cull(p, c.view, &depth);
+            project_splat(c, p, cov6, opac, depth, &sp);  // as in the first sweep: succeeds, same values
+            V3 col = sh_to_rgb(b.D, p, v3(c.campos[0], c.campos[1], c.campos[2]), sh);
+            bv.clamped[i] = (uint8_t)((col.x < 0 ? 1 : 0) | (col.y < 0 ? 2 : 0) | (col.z < 0 ? 4 : 0));
+            col = v3(fmax_(col.x, 0.0f), fmax_(col.y, 0.0f), fmax_(col.z, 0.0f));
+            float4* r4 = reinterpret_cast<float4*>(bv.rec + i);
+            r4[0] = make_float4(sp.xy.x, sp.xy.y, sp.conic_opacity.x, sp.conic_opacity.y);
+            r4[1] = make_float4(sp.conic_opacity.z, sp.conic_opacity.w, col.x, col.y);
+            r4[2] = make_float4(col.z, 1 / sp.depth, rp.x, rp.y);
+            r4[3] = make_float4(rp.z, rp.w, sp.depth, 0.0f);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < b.nviews) {
+        const int v = threadIdx.x;
+        b.v[v].block_sums[blockIdx.x] = s_tiles[v][0] + s_tiles[v][1] + s_tiles[v][2] + s_tiles[v][3];
+        b.v[v].vis_sums[blockIdx.x] = s_vis[v][0] + s_vis[v][1] + s_vis[v][2] + s_vis[v][3];
+    }
+}
+
 // Exclusive scan of the per-block sums, total instance count into total[0],
 // overflow flag into total[1].  One workgroup of 1024 threads, 16 consecutive
 // sums per thread and step, so 23 k sums (6 M Gaussians) take two steps; the
@@ -332,6 +486,30 @@ hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, cons
     a.vis_sums = g.vis_sums;
     const int nb = (s.P + PRE_BLOCK - 1) / PRE_BLOCK;
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_preprocess_fwd_batch(const GsrScene& s, int nviews, const GsrForwardView* views, hipStream_t st) {
+    PreBatchArgs b;
+    b.P = s.P; b.D = s.D; b.M = s.M; b.DIM = s.DIM;
+    b.mod = s.scale_modifier; b.raw = s.raw_params;
+    b.means3D = s.means3D; b.shs = s.shs; b.shs_rest = s.shs_rest; b.opacities = s.opacities;
+    b.scales = s.scales; b.rotations = s.rotations; b.reps = s.reps;
+    const int nb = (s.P + PRE_BLOCK - 1) / PRE_BLOCK;
+    for (int v0 = 0; v0 < nviews; v0 += MAX_FWD_BATCH_VIEWS) {
+        b.nviews = nviews - v0 < MAX_FWD_BATCH_VIEWS ? nviews - v0 : MAX_FWD_BATCH_VIEWS;
+        for (int k = 0; k < b.nviews; ++k) {
+            const GsrForwardView& fv = views[v0 + k];
+            const GeomBuf g = geom_buf(fv.geom_buffer, (size_t)s.P);
+            FwdBatchView& bv = b.v[k];
+            bv.cam.view = fv.viewmatrix; bv.cam.proj = fv.projmatrix; bv.cam.campos = fv.campos;
+            bv.tanx = fv.tanfovx; bv.tany = fv.tanfovy; bv.W = fv.W; bv.H = fv.H; bv.aa = fv.antialiasing;
+            bv.radii = fv.radii; bv.out_depths = fv.out_depths;
+            bv.rec = g.rec; bv.bin = g.bin; bv.gstat = g.gstat; bv.clamped = g.clamped;
+            bv.block_sums = g.block_sums; bv.vis_sums = g.vis_sums;
+        }
+        hipLaunchKernelGGL(preprocess_fwd_batch_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, b);
+    }
     return hipGetLastError();
 }
 

@@ -250,6 +250,45 @@ __device__ __forceinline__ void sh_rows_add(float* __restrict__ g, const float4*
     }
 }
 
+constexpr int REST_ROW_F = 45;              // dwords per row of the [P,15,3] tensor
+constexpr int REST_WAVE_F = 64 * REST_ROW_F;  // 2880 dwords = 11520 bytes per wave
+
+// The wave's block of the [P,15,3] tensor (nrows x 45 dwords, contiguous, 16-byte
+// aligned because a wave starts at a multiple of 64 rows) between global memory
+// and its linear LDS image, 16 bytes per lane and step.  A chunk can straddle
+// two rows; it moves if either row's bit is set in `rows`.
+// OP 0: LDS = global, 1: global = LDS, 2: global += LDS.
+template <int OP>
+__device__ __forceinline__ void rest_rows_copy(float* __restrict__ g, float* lds, uint64_t rows, int nrows, int lane) {
+    const int total = nrows * REST_ROW_F;
+    float4* g4 = reinterpret_cast<float4*>(g);
+    float4* l4 = reinterpret_cast<float4*>(lds);
+#pragma unroll
+    for (int it = 0; it < (REST_WAVE_F / 4 + 63) / 64; ++it) {
+        const int i = it * 64 + lane;
+        if (4 * i + 3 < total) {
+            const int r0 = (4 * i) / REST_ROW_F, r1 = (4 * i + 3) / REST_ROW_F;
+            if (((rows >> r0) | (rows >> r1)) & 1ull) {
+                if (OP == 0) {
+                    l4[i] = g4[i];
+                } else if (OP == 1) {
+                    g4[i] = l4[i];
+                } else {
+                    const float4 o = g4[i], v = l4[i];
+                    g4[i] = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+                }
+            }
+        }
+    }
+    // up to three dwords left when the last wave is partial
+    const int f = (total & ~3) + lane;
+    if (lane < 3 && f < total && ((rows >> (f / REST_ROW_F)) & 1ull)) {
+        if (OP == 0) lds[f] = g[f];
+        else if (OP == 1) g[f] = lds[f];
+        else g[f] += lds[f];
+    }
+}
+
 // One lane's row between LDS and registers.
 __device__ __forceinline__ void sh_row_get(const float4* lds, int lane, float (&v)[SH_ROW_F]) {
 #pragma unroll

@@ -65,6 +65,9 @@ static_assert(sizeof(GradRec) == 64, "GradRec must be 64 bytes");
 int sort_passes_for(int begin_bit, int end_bit);
 
 hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, const GeomBuf& g, hipStream_t st);
+// The preprocess of several views in one pass over the Gaussians (everything launch_preprocess_fwd
+// leaves in a view's geometry buffer except the 3D covariance).
+hipError_t launch_preprocess_fwd_batch(const GsrScene& s, int nviews, const GsrForwardView* views, hipStream_t st);
 // Exclusive scans of the per-block tile sums and visible counts; totals into g.total.
 hipError_t launch_scan_blocks(const GeomBuf& g, int nb, hipStream_t st);
 // Depth keys of the n Gaussians to order (n = number with instances: compacted; n = P: all of them),

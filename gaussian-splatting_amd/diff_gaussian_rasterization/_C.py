@@ -7,8 +7,8 @@ import ctypes as C
 
 import torch
 
-from _gsplat_lib import (GsrBackwardIO, GsrBackwardView, GsrForwardOut, GsrScene, check, dev_f32, lib, profile_events,
-                         ptr, stream_of)
+from _gsplat_lib import (GsrBackwardIO, GsrBackwardView, GsrForwardOut, GsrForwardView, GsrScene, check, dev_f32, lib,
+                         profile_events, ptr, stream_of)
 
 SUPPORTED_DIMS = (0, 4)
 
@@ -51,7 +51,7 @@ def _check_shapes(means3D, reps):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, antialiasing, debug, reps=None, sh_rest=None, raw_params=False):
+                        prefiltered, antialiasing, debug, reps=None, sh_rest=None, raw_params=False, prepared=None):
     """rasterize_points.cu:35-206.  Returns (num_rendered, color, radii,
     geomBuffer, binningBuffer, imgBuffer, invdepth, accum_alpha, gauss_sum,
     gauss_count, last_contr_gauss, out_depths, out_reps).
@@ -59,7 +59,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     Beyond the reference: `sh_rest` (then `sh` is the [P,1,3] DC tensor and
     `sh_rest` the [P,M-1,3] remainder, uncatenated) and `raw_params` (opacity
     logits, log-scales and unnormalised rotations; the kernels apply the
-    activations of scene/gaussian_model.py:41-53)."""
+    activations of scene/gaussian_model.py:41-53); `prepared` = this view's
+    entry of what `preprocess_batch` returned for the same parameters (the
+    preprocess kernel is then skipped)."""
     _check_shapes(means3D, reps)
     if not means3D.is_cuda:
         raise RuntimeError("means3D must be a GPU tensor (there is no CPU path)")
@@ -77,14 +79,16 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         u8 = dict(dtype=torch.uint8, device=dev)
         out_color = torch.empty((3, H, W), **f32)
         out_invdepth = torch.empty((1, H, W), **f32)
-        radii = torch.empty((P,), **i32)
+        radii = prepared["radii"] if prepared else torch.empty((P,), **i32)
         accum_alpha = torch.empty((1, H, W), **f32)
         gauss_sum = torch.empty((P,), **f32)
         gauss_count = torch.empty((P,), **i32)
         last_contr = torch.empty((1, H, W), **i32)
-        out_depths = torch.empty((P,), **f32)
+        out_depths = prepared["out_depths"] if prepared else torch.empty((P,), **f32)
         out_reps = torch.empty((DIM, H, W), **f32)
-        geom = torch.empty((L.gsr_geom_bytes(P),), **u8)
+        geom = prepared["geom"] if prepared else torch.empty((L.gsr_geom_bytes(P),), **u8)
+        if prepared and (radii.numel() != P or geom.numel() < L.gsr_geom_bytes(P) or geom.device != dev):
+            raise RuntimeError("`prepared` does not belong to these parameters")
         img = torch.empty((L.gsr_image_bytes(W, H),), **u8)
         o = GsrForwardOut()
         o.out_color, o.out_invdepth, o.radii = ptr(out_color), ptr(out_invdepth), ptr(radii)
@@ -92,6 +96,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         o.last_contr_gauss, o.out_depths, o.out_reps = ptr(last_contr), ptr(out_depths), ptr(out_reps)
         o.geom_buffer, o.geom_bytes = ptr(geom), geom.numel()
         o.image_buffer, o.image_bytes = ptr(img), img.numel()
+        o.preprocessed = 1 if prepared else 0
         st = stream_of(dev)
         R = C.c_int64(0)
         check(L.gsr_forward_stage1(C.byref(s), C.byref(o), st, C.byref(R)), "rasterize_gaussians (stage 1)")
@@ -253,6 +258,47 @@ def backward_geometry_batch(means3D, opacities, scales, rotations, scale_modifie
         io.accumulate = int(bool(accumulate))
         check(L.gsr_backward_geometry_batch(C.byref(s), len(views), arr, C.byref(io), stream_of(dev)),
               "backward_geometry_batch")
+
+
+def preprocess_batch(means3D, opacities, scales, rotations, scale_modifier, sh, sh_rest, degree, reps, raw_params,
+                     views, debug=False):
+    """The forward preprocess of several views in one pass over the Gaussians
+    (no counterpart in the reference).  `views` is a list of
+    GaussianRasterizationSettings-like objects (viewmatrix, projmatrix, campos,
+    tanfovx, tanfovy, image_width, image_height, antialiasing); returns one dict
+    per view (radii, out_depths, geom) to hand to `rasterize_gaussians(...,
+    prepared=...)` while the parameters are unchanged."""
+    L = lib()
+    dev = means3D.device
+    P = means3D.size(0)
+    out = []
+    if not views:
+        return out
+    keep = []
+    with torch.cuda.device(dev):
+        v0 = views[0]
+        s = _scene(None, means3D, None, opacities, scales, rotations, scale_modifier, None, v0.viewmatrix,
+                   v0.projmatrix, v0.tanfovx, v0.tanfovy, v0.image_height, v0.image_width, sh, degree, v0.campos, False,
+                   False, debug, reps, keep, sh_rest=sh_rest, raw=raw_params)
+        arr = (GsrForwardView * len(views))()
+        nbytes = L.gsr_geom_bytes(P)
+        for k, v in enumerate(views):
+            for name in ("viewmatrix", "projmatrix", "campos"):
+                c = dev_f32(getattr(v, name), dev, name)
+                keep.append(c)
+                setattr(arr[k], name, ptr(c))
+            arr[k].tanfovx, arr[k].tanfovy = float(v.tanfovx), float(v.tanfovy)
+            arr[k].W, arr[k].H = int(v.image_width), int(v.image_height)
+            arr[k].antialiasing = int(bool(v.antialiasing))
+            d = dict(radii=torch.empty((P,), dtype=torch.int32, device=dev),
+                     out_depths=torch.empty((P,), dtype=torch.float32, device=dev),
+                     geom=torch.empty((nbytes,), dtype=torch.uint8, device=dev))
+            arr[k].radii, arr[k].out_depths = d["radii"].data_ptr(), d["out_depths"].data_ptr()
+            arr[k].geom_buffer, arr[k].geom_bytes = d["geom"].data_ptr(), nbytes
+            out.append(d)
+        if P != 0:
+            check(L.gsr_preprocess_batch(C.byref(s), len(views), arr, stream_of(dev)), "preprocess_batch")
+    return out
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

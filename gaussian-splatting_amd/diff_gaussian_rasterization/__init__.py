@@ -115,11 +115,41 @@ class ParamGradSink:
             features_dc.size(1) + features_rest.size(1) == 16
         self.pending = []
         self.pending_cfg = None
+        self.prepared = []
 
     def begin_step(self):
         """The next backward overwrites the buffers, the ones after it accumulate."""
         self.pending = []
+        self.prepared = []
         self.fresh = True
+
+    def prepare_views(self, settings_list):
+        """Run the forward preprocess of the views that are going to be rendered from the current
+        parameter values (e.g. all the views of this optimiser step) in one pass over the
+        Gaussians: parameters and SH rows are read once instead of once per view.  The following
+        `forward_params(..., grad_sink=self)` calls whose `raster_settings` is one of these
+        objects pick their share up; results are identical to unprepared calls.  Only valid
+        while the parameters keep their values (`begin_step()` drops what was not used).
+        Needs 16 SH coefficients; otherwise does nothing."""
+        p = self.params
+        if not settings_list or "sh_rest" not in self.grads or p["sh"].size(1) + p["sh_rest"].size(1) != 16:
+            return
+        groups = {}   # one call per (scale modifier, degree): the rest is per view
+        for rs in settings_list:
+            groups.setdefault((float(rs.scale_modifier), int(rs.sh_degree), bool(rs.debug)), []).append(rs)
+        empty = torch.Tensor([])
+        for (mod, degree, debug), views in groups.items():
+            res = _C.preprocess_batch(p["means3D"], p["opacity"], p["scales"], p["rotations"], mod, p["sh"],
+                                      p["sh_rest"], degree, empty if p["reps"] is None else p["reps"], True, views,
+                                      debug)
+            self.prepared.extend(zip(views, res))
+
+    def take_prepared(self, rs):
+        for k, (v, d) in enumerate(self.prepared):
+            if v is rs:
+                del self.prepared[k]
+                return d
+        return None
 
     def flush(self):
         """Run the per-Gaussian backward of the views whose backward was deferred."""
@@ -152,11 +182,13 @@ class _RasterizeGaussiansParams(torch.autograd.Function):
                 sink):
         rs = raster_settings
         empty = torch.Tensor([])
+        prepared = sink.take_prepared(rs) if sink is not None else None
         (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths, accum_alpha, gauss_sum,
          gauss_count, last_contr_gauss, depths, out_reps) = _C.rasterize_gaussians(
             rs.bg, xyz, empty, opacity, scaling, rotation, rs.scale_modifier, empty, rs.viewmatrix, rs.projmatrix,
             rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, features_dc, rs.sh_degree, rs.campos,
-            rs.prefiltered, rs.antialiasing, rs.debug, reps, sh_rest=features_rest, raw_params=True)
+            rs.prefiltered, rs.antialiasing, rs.debug, reps, sh_rest=features_rest, raw_params=True,
+            prepared=prepared)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.sink = sink

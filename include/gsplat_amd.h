@@ -106,7 +106,9 @@ typedef enum {
     GSR_EV_BWD_PREPROCESS = 13,/* per-Gaussian backward (gsr_backward) or screen-space gradient copy (gsr_backward_blend) */
     GSR_EV_BATCH_BEGIN = 14,
     GSR_EV_BATCH = 15,         /* per-Gaussian backward of a batch of views (gsr_backward_geometry_batch) */
-    GSR_NUM_PROFILE_EVENTS = 16
+    GSR_EV_FWD_BATCH_BEGIN = 16,
+    GSR_EV_FWD_BATCH = 17,     /* preprocess of a batch of views (gsr_preprocess_batch) */
+    GSR_NUM_PROFILE_EVENTS = 18
 } GsrProfileEvent;
 
 /* Outputs of the forward pass.  None of them needs initialising by the caller. */
@@ -127,6 +129,8 @@ typedef struct {
     int64_t num_visible;     /* written by gsr_forward_stage1, read by gsr_forward_stage2 (same struct): Gaussians
                                 that produce at least one instance; stage 2 orders only those by depth.  A value
                                 < 0 there means "not known" and all P are ordered. */
+    int preprocessed;        /* nonzero: geom_buffer, radii and out_depths were filled by gsr_preprocess_batch for
+                                this view; gsr_forward_stage1 then only runs the prefix sums */
 } GsrForwardOut;
 
 /* Gradients.  Inputs are the three per-pixel gradients; every output is fully
@@ -198,6 +202,29 @@ int gsr_backward_blend(const GsrScene* scene, const int* radii, const void* geom
                        const void* image_buffer, int64_t num_rendered, const GsrBackwardIO* io, void* stream);
 int gsr_backward_geometry_batch(const GsrScene* scene, int nviews, const GsrBackwardView* views,
                                 const GsrBackwardIO* io, void* stream);
+
+/* Forward preprocess of a batch of views in one pass over the Gaussians (no counterpart in the
+ * reference, which renders one view per iteration; for callers that render several views from the
+ * same parameters, e.g. the views of one optimiser step).  Each Gaussian's parameters and SH row are
+ * read once for all the views; per view the call leaves in geom_buffer, radii and out_depths exactly
+ * what the preprocess of gsr_forward_stage1 would (bit for bit), except the 3D covariance, which the
+ * backward recomputes.  Afterwards run gsr_forward_stage1 / stage2 per view with
+ * GsrForwardOut.preprocessed = 1 and the same three buffers.  Needs the SH tensors split
+ * (scene->shs_rest), M == 16 and scales + rotations; the camera fields, W, H and antialiasing of
+ * `scene` are ignored (each view brings its own). */
+typedef struct {
+    const float* viewmatrix;   /* device [16] */
+    const float* projmatrix;   /* device [16] */
+    const float* campos;       /* device [3] */
+    float tanfovx, tanfovy;
+    int W, H;
+    int antialiasing;
+    int* radii;                /* device [P], out */
+    float* out_depths;         /* device [P], out (written where radii > 0) */
+    void* geom_buffer;         /* device, >= gsr_geom_bytes(P), out */
+    size_t geom_bytes;
+} GsrForwardView;
+int gsr_preprocess_batch(const GsrScene* scene, int nviews, const GsrForwardView* views, void* stream);
 
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
                      void* stream);

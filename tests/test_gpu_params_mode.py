@@ -284,3 +284,113 @@ def test_deferred_batch_backward_matches_per_view_backward(oracle, nviews):
     assert rel_err(got_sh, tot["sh"]) <= REL_TOL
     for n in ("xyz", "opacity", "scaling", "rotation", "reps"):
         assert rel_err(B[n].grad.cpu().numpy().reshape(tot[n].shape), tot[n]) <= REL_TOL, n
+
+
+def _arc_settings(nviews, W, H, aa=True, debug=True):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda:0")
+    out = []
+    for v in range(nviews):
+        ang = 0.25 * (v - nviews / 2)
+        cam = synth.make_camera(W, H, 0.9, (0.1 + 2.5 * np.sin(ang), -0.05 + 0.1 * v, -2.5 * np.cos(ang)), (0.0, 0.0, 1.0))
+        out.append(GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=t((0.1, 0.2, 0.3)),
+            scale_modifier=1.0, viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=3,
+            campos=t(cam["campos"]), prefiltered=False, debug=debug, antialiasing=aa))
+    return out
+
+
+@pytest.mark.parametrize("nviews,P", [(1, 300), (3, 500), (11, 777)])
+def test_batched_forward_preprocess_is_bit_identical(nviews, P):
+    """gsr_preprocess_batch + stage 1/2 with `preprocessed` set leaves every output and every
+    scratch array that later stages read exactly as the one-view preprocess does."""
+    from diff_gaussian_rasterization import _C
+    W, H = 96, 64
+    sc = synth.tiny_scene(P=P, width=W, height=H, seed=31)
+    raw = _raw_scene(sc, seed=5)
+    settings = _arc_settings(nviews, W, H)
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda:0")
+    ten = dict(xyz=t(sc["means3D"]), dc=t(raw["features_dc"]), rest=t(raw["features_rest"]), opacity=t(raw["opacity"]),
+               scaling=t(raw["scaling"]), rotation=t(raw["rotation"]), reps=t(sc["reps"]))
+    e = torch.Tensor([])
+    names = ("num_rendered", "color", "radii", "geom", "binning", "img", "invdepth", "accum_alpha", "gauss_sum",
+             "gauss_count", "last_contr_gauss", "out_depths", "out_reps")
+
+    def fwd(rs, prepared):
+        return dict(zip(names, _C.rasterize_gaussians(
+            rs.bg, ten["xyz"], e, ten["opacity"], ten["scaling"], ten["rotation"], rs.scale_modifier, e, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, ten["dc"], rs.sh_degree, rs.campos,
+            False, rs.antialiasing, rs.debug, ten["reps"], sh_rest=ten["rest"], raw_params=True, prepared=prepared)))
+
+    prep = _C.preprocess_batch(ten["xyz"], ten["opacity"], ten["scaling"], ten["rotation"], 1.0, ten["dc"], ten["rest"], 3,
+                               ten["reps"], True, settings, debug=True)
+    assert len(prep) == nviews
+    seen_any = 0
+    for rs, pr in zip(settings, prep):
+        a = fwd(rs, None)
+        b = fwd(rs, pr)
+        torch.cuda.synchronize()
+        assert a["num_rendered"] == b["num_rendered"]
+        seen_any += a["num_rendered"]
+        vis = a["radii"].cpu().numpy() > 0
+        for k in ("color", "radii", "invdepth", "accum_alpha", "gauss_count", "last_contr_gauss", "out_reps"):
+            assert torch.equal(a[k], b[k]), k
+        assert rel_err(b["gauss_sum"].cpu().numpy(), a["gauss_sum"].cpu().numpy()) <= REL_TOL   # float atomics
+        assert np.array_equal(a["out_depths"].cpu().numpy()[vis], b["out_depths"].cpu().numpy()[vis])
+        ia, ib = read_internals(a, P, W, H), read_internals(b, P, W, H)
+        assert np.array_equal(ia["rec"][vis][:, :15], ib["rec"][vis][:, :15])
+        assert np.array_equal(ia["bin"], ib["bin"])
+        assert np.array_equal(ia["clamped"][vis], ib["clamped"][vis])
+        for k in ("keys", "point_list", "n_contrib", "ranges", "final_T"):
+            assert np.array_equal(ia[k], ib[k]), k
+    assert seen_any > 0
+
+
+@pytest.mark.parametrize("defer", [False, True], ids=["per_view_backward", "deferred_backward"])
+def test_prepared_views_give_the_same_gradients(defer):
+    """ParamGradSink.prepare_views in front of the views of a step: same images, same gradients
+    (the backward of a prepared view recomputes the 3D covariance instead of reading it)."""
+    from diff_gaussian_rasterization import GaussianRasterizer, ParamGradSink
+    nviews, W, H = 4, 96, 64
+    sc = synth.tiny_scene(P=600, width=W, height=H, seed=37)
+    raw = _raw_scene(sc, seed=6)
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda:0")
+    names = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation", "reps")
+    vals = (sc["means3D"], raw["features_dc"], raw["features_rest"], raw["opacity"], raw["scaling"], raw["rotation"],
+            sc["reps"])
+    A = {n: t(v).requires_grad_(True) for n, v in zip(names, vals)}
+    B = {n: t(v).requires_grad_(True) for n, v in zip(names, vals)}
+    sink_a = ParamGradSink(*[A[n] for n in names], defer=defer)
+    sink_b = ParamGradSink(*[B[n] for n in names], defer=defer)
+    settings = _arc_settings(nviews, W, H)
+    rng = np.random.default_rng(11)
+    ws = [[t(rng.standard_normal(s).astype(np.float32)) for s in ((3, H, W), (1, H, W), (4, H, W))] for _ in range(nviews)]
+
+    def run(P_, sink, prepare):
+        sink.begin_step()
+        if prepare:
+            sink.prepare_views(settings)
+            assert len(sink.prepared) == nviews
+        imgs, m2s = [], []
+        for v in range(nviews):
+            m2 = torch.zeros_like(P_["xyz"], requires_grad=True)
+            o = GaussianRasterizer(settings[v]).forward_params(
+                P_["xyz"], m2, P_["features_dc"], P_["features_rest"], P_["opacity"], P_["scaling"], P_["rotation"],
+                P_["reps"], grad_sink=sink)
+            ((o[0] * ws[v][0]).sum() + (o[2] * ws[v][1]).sum() + (o[5] * ws[v][2]).sum()).backward()
+            imgs.append(o[0].detach().clone())
+            m2s.append(m2)
+        sink.flush()
+        assert not sink.prepared
+        return imgs, [m.grad.clone() for m in m2s]
+
+    ia, ma = run(A, sink_a, False)
+    ib, mb = run(B, sink_b, True)
+    for x, y in zip(ia, ib):
+        assert torch.equal(x, y)
+    for x, y in zip(ma, mb):
+        assert rel_err(y.cpu().numpy(), x.cpu().numpy()) <= REL_TOL
+    for n in names:
+        ga, gb = A[n].grad.cpu().numpy(), B[n].grad.cpu().numpy()
+        assert np.isfinite(gb).all(), n
+        assert rel_err(gb, ga) <= REL_TOL, (n, rel_err(gb, ga))
