@@ -127,14 +127,10 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs
 // and SH row are read once for all the views of an optimiser step instead of
 // once per view; per view only the results are written.  The same functions in
 // the same order as preprocess_fwd_kernel: every per-view array comes out bit
-// for bit as from the one-view kernel.  Two sweeps over the views: the first
-// projects the Gaussian into every view and writes the small per-Gaussian
-// arrays (radius, tile rectangle, depth), which tells whether any view renders
-// it and hence whether its SH row has to be fetched; the second repeats the
-// projection for the views that do (arithmetic is cheap here, the kernel waits
-// on memory) and writes each 64-byte SplatRec whole, colour included: filling
-// the colour into records written in the first sweep cost a partial-line
-// write per record and view.
+// for bit as from the one-view kernel.  The kernel is bound by its arithmetic
+// (about 650 instructions per Gaussian and view, most of them the projection),
+// not by memory: everything is computed once, and each 64-byte SplatRec is
+// written whole.
 // Needs [P,1,3] + [P,15,3] SH tensors and scales + rotations; the 3D covariance
 // is not stored (the backward recomputes it from scale and rotation).
 constexpr int MAX_FWD_BATCH_VIEWS = 8;
@@ -196,8 +192,37 @@ __global__ void __launch_bounds__(PRE_BLOCK, 2) preprocess_fwd_batch_kernel(cons
         cov3d_from_scale_rot(sc, b.mod, q, cov6);
     }
 
-    // First sweep: which views render this Gaussian, and the small per-Gaussian arrays.
-    uint32_t seen = 0;  // bit v: view v renders it
+    // The SH row is fetched for every Gaussian that lies in front of at least one camera (the near
+    // test of the preprocess; cheap).  Some of those turn out to be off screen in every view and
+    // their row was fetched for nothing, which costs less than finding out exactly: that would
+    // take the whole projection, once more per view.
+    bool maybe = false;
+    if (live) {
+#pragma unroll 1
+        for (int v = 0; v < b.nviews; ++v) {
+            float vm[16], depth;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) vm[k] = b.v[v].cam.view[k];
+            maybe = maybe || !near_cull(p, vm, &depth);
+        }
+    }
+    const uint64_t rows = __ballot(maybe);
+    if (rows && nrows > 0)
+        rest_rows_copy<0>(const_cast<float*>(b.shs_rest) + (size_t)wave_g0 * REST_ROW_F, lds, rows, nrows, lane);
+    wave_lds_sync();
+    // coefficient 0 from registers, the others from the lane's row in LDS (row stride 45 dwords: odd,
+    // no bank conflicts); keeping the row out of the registers leaves them to the projection
+    struct ShRow {
+        float dc0, dc1, dc2;
+        const float* row;
+        __device__ __forceinline__ V3 operator()(int k) const {
+            return k == 0 ? v3(dc0, dc1, dc2) : v3(row[3 * k - 3], row[3 * k - 2], row[3 * k - 1]);
+        }
+    };
+    const ShRow sh = {b.shs[3 * i], b.shs[3 * i + 1], b.shs[3 * i + 2], lds + lane * REST_ROW_F};
+    float4 rp = make_float4(0, 0, 0, 0);
+    if (b.DIM == 4) rp = reinterpret_cast<const float4*>(b.reps)[i];
+
 #pragma unroll 1
     for (int v = 0; v < b.nviews; ++v) {
         const FwdBatchView& bv = b.v[v];
@@ -210,6 +235,14 @@ __global__ void __launch_bounds__(PRE_BLOCK, 2) preprocess_fwd_batch_kernel(cons
             if (!near_cull(p, c.view, &depth)) {
                 Splat sp;
                 if (project_splat(c, p, cov6, opac, depth, &sp)) {
+                    V3 col = sh_to_rgb(b.D, p, v3(c.campos[0], c.campos[1], c.campos[2]), sh);
+                    bv.clamped[i] = (uint8_t)((col.x < 0 ? 1 : 0) | (col.y < 0 ? 2 : 0) | (col.z < 0 ? 4 : 0));
+                    col = v3(fmax_(col.x, 0.0f), fmax_(col.y, 0.0f), fmax_(col.z, 0.0f));
+                    float4* r4 = reinterpret_cast<float4*>(bv.rec + i);
+                    r4[0] = make_float4(sp.xy.x, sp.xy.y, sp.conic_opacity.x, sp.conic_opacity.y);
+                    r4[1] = make_float4(sp.conic_opacity.z, sp.conic_opacity.w, col.x, col.y);
+                    r4[2] = make_float4(col.z, 1 / sp.depth, rp.x, rp.y);
+                    r4[3] = make_float4(rp.z, rp.w, sp.depth, 0.0f);
                     bv.out_depths[i] = sp.depth;
                     radius = sp.radius;
                     tiles = sp.tiles;
@@ -217,7 +250,6 @@ __global__ void __launch_bounds__(PRE_BLOCK, 2) preprocess_fwd_batch_kernel(cons
                     bin.y = (uint32_t)(sp.rect.x1 - sp.rect.x0) | ((uint32_t)(sp.rect.y1 - sp.rect.y0) << 16);
                     bin.z = f2bits(sp.depth);
                     bin.w = tiles;
-                    seen |= 1u << v;
                 }
             }
             bv.radii[i] = radius;
@@ -229,42 +261,6 @@ __global__ void __launch_bounds__(PRE_BLOCK, 2) preprocess_fwd_batch_kernel(cons
         if (lane == 0) {
             s_tiles[v][w] = ws;
             s_vis[v][w] = wv;
-        }
-    }
-
-    // Second sweep: the SplatRec of every view that renders it, colour included.
-    const uint64_t rows = __ballot(seen != 0);
-    if (rows && nrows > 0)
-        rest_rows_copy<0>(const_cast<float*>(b.shs_rest) + (size_t)wave_g0 * REST_ROW_F, lds, rows, nrows, lane);
-    wave_lds_sync();
-    if (seen) {
-        float shv[SH_ROW_F];
-        shv[0] = b.shs[3 * i];
-        shv[1] = b.shs[3 * i + 1];
-        shv[2] = b.shs[3 * i + 2];
-        const float* row = lds + lane * REST_ROW_F;
-#pragma unroll
-        for (int k = 0; k < REST_ROW_F; ++k) shv[3 + k] = row[k];
-        const ShRegs sh = {shv};
-        float4 rp = make_float4(0, 0, 0, 0);
-        if (b.DIM == 4) rp = reinterpret_cast<const float4*>(b.reps)[i];
-#pragma unroll 1
-        for (int v = 0; v < b.nviews; ++v) {
-            if (!((seen >> v) & 1u)) continue;
-            const FwdBatchView& bv = b.v[v];
-            const Cam c = load_cam(bv.cam, bv.W, bv.H, bv.tanx, bv.tany, b.mod, b.D, b.M, bv.aa);
-            float depth;
-            Splat sp;
-            near_cull(p, c.view, &depth);
-            project_splat(c, p, cov6, opac, depth, &sp);  // as in the first sweep: succeeds, same values
-            V3 col = sh_to_rgb(b.D, p, v3(c.campos[0], c.campos[1], c.campos[2]), sh);
-            bv.clamped[i] = (uint8_t)((col.x < 0 ? 1 : 0) | (col.y < 0 ? 2 : 0) | (col.z < 0 ? 4 : 0));
-            col = v3(fmax_(col.x, 0.0f), fmax_(col.y, 0.0f), fmax_(col.z, 0.0f));
-            float4* r4 = reinterpret_cast<float4*>(bv.rec + i);
-            r4[0] = make_float4(sp.xy.x, sp.xy.y, sp.conic_opacity.x, sp.conic_opacity.y);
-            r4[1] = make_float4(sp.conic_opacity.z, sp.conic_opacity.w, col.x, col.y);
-            r4[2] = make_float4(col.z, 1 / sp.depth, rp.x, rp.y);
-            r4[3] = make_float4(rp.z, rp.w, sp.depth, 0.0f);
         }
     }
     __syncthreads();
