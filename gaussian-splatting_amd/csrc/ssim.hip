@@ -5,8 +5,11 @@
 // One 256-thread workgroup produces a 32x32 output tile of one image plane:
 // the 42x42 halo of the inputs goes to LDS once, the horizontal pass writes
 // all filtered moments of the 42 halo rows back to LDS, the vertical pass
-// reads them column-wise (consecutive lanes -> consecutive banks).  HBM-bound:
-// forward 6 planes, backward 7 planes of 4 bytes per pixel.
+// reads them column-wise (consecutive lanes -> consecutive banks).  Both passes
+// compute four neighbouring outputs per thread from a sliding window of 14
+// inputs, which cuts the LDS reads per output from 11 to 3.5 (the kernels were
+// bound by LDS reads and barriers, not by the 6 / 7 planes of HBM traffic);
+// every output still accumulates its taps in the order G_00..G_10.
 #include "kernels.h"
 
 namespace gs {
@@ -24,7 +27,7 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, float C1, f
                                                        float* __restrict__ dm_dsigma12) {
     __shared__ float s_a[SS_H][SS_H + 1];
     __shared__ float s_b[SS_H][SS_H + 1];
-    __shared__ float s_x[5][SS_H][SS_T];  // mu1, E[x^2], mu2, E[y^2], E[xy] after the horizontal pass
+    __shared__ __align__(16) float s_x[5][SS_H][SS_T];  // mu1, E[x^2], mu2, E[y^2], E[xy] after the horizontal pass
     const size_t plane = (size_t)blockIdx.z * H * W;
     const float* a = img1 + plane;
     const float* b = img2 + plane;
@@ -37,40 +40,61 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, float C1, f
         s_b[ly][lx] = ssim_ld(b, y0 + ly - 5, x0 + lx - 5, H, W);
     }
     __syncthreads();
-    for (int i = tid; i < SS_H * SS_T; i += 256) {
-        const int ly = i / SS_T, lx = i - ly * SS_T;
-        float m1 = 0.f, e1 = 0.f, m2 = 0.f, e2 = 0.f, e12 = 0.f;
+    for (int i = tid; i < SS_H * (SS_T / 4); i += 256) {
+        const int ly = i / (SS_T / 4), lx = (i - ly * (SS_T / 4)) * 4;
+        float v[5][4];
 #pragma unroll
-        for (int k = 0; k < GS_SSIM_TAPS; ++k) {
-            const float g = ssim_tap(k);
-            const float pa = s_a[ly][lx + k], pb = s_b[ly][lx + k];
-            m1 += g * pa;
-            e1 += g * (pa * pa);
-            m2 += g * pb;
-            e2 += g * (pb * pb);
-            e12 += g * (pa * pb);
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[c][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < GS_SSIM_TAPS + 3; ++j) {
+            const float pa = s_a[ly][lx + j], pb = s_b[ly][lx + j];
+            const float aa = pa * pa, bb = pb * pb, ab = pa * pb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = j - r;  // output lx + r sees this input as its tap k
+                if (k >= 0 && k < GS_SSIM_TAPS) {
+                    const float g = ssim_tap(k);
+                    v[0][r] += g * pa;
+                    v[1][r] += g * aa;
+                    v[2][r] += g * pb;
+                    v[3][r] += g * bb;
+                    v[4][r] += g * ab;
+                }
+            }
         }
-        s_x[0][ly][lx] = m1;
-        s_x[1][ly][lx] = e1;
-        s_x[2][ly][lx] = m2;
-        s_x[3][ly][lx] = e2;
-        s_x[4][ly][lx] = e12;
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+            *reinterpret_cast<float4*>(&s_x[c][ly][lx]) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
     }
     __syncthreads();
-    const int lx = tid & 31;
+    const int lx = tid & 31, ly0 = (tid >> 5) * 4;
+    float v[5][4];
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[c][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < GS_SSIM_TAPS + 3; ++j) {
+        float in[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) in[c] = s_x[c][ly0 + j][lx];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = j - r;
+            if (k >= 0 && k < GS_SSIM_TAPS) {
+                const float g = ssim_tap(k);
+#pragma unroll
+                for (int c = 0; c < 5; ++c) v[c][r] += g * in[c];
+            }
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int ly = (tid >> 5) + 8 * r;
-        float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < GS_SSIM_TAPS; ++k) {
-            const float g = ssim_tap(k);
-#pragma unroll
-            for (int c = 0; c < 5; ++c) v[c] += g * s_x[c][ly + k][lx];
-        }
-        const int px = x0 + lx, py = y0 + ly;
+        const int px = x0 + lx, py = y0 + ly0 + r;
         if (px < W && py < H) {
-            const SsimOut o = ssim_point(v[0], v[1], v[2], v[3], v[4], C1, C2);
+            const SsimOut o = ssim_point(v[0][r], v[1][r], v[2][r], v[3][r], v[4][r], C1, C2);
             const size_t gi = plane + (size_t)py * W + px;
             ssim_map[gi] = o.m;
             if (dm_dmu1) {
@@ -89,7 +113,7 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, const float
                                                        const float* __restrict__ dm_dsigma1_sq,
                                                        const float* __restrict__ dm_dsigma12) {
     __shared__ float s_p[3][SS_H][SS_H + 1];  // dL * (dm_dmu1, dm_dsigma1_sq, dm_dsigma12)
-    __shared__ float s_x[3][SS_H][SS_T];
+    __shared__ __align__(16) float s_x[3][SS_H][SS_T];
     const size_t plane = (size_t)blockIdx.z * H * W;
     const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
     const int tid = threadIdx.x;
@@ -102,37 +126,63 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, const float
         s_p[2][ly][lx] = ssim_ld(dm_dsigma12 + plane, y, x, H, W) * dl;
     }
     __syncthreads();
-    for (int i = tid; i < SS_H * SS_T; i += 256) {
-        const int ly = i / SS_T, lx = i - ly * SS_T;
-        float v[3] = {0.f, 0.f, 0.f};
+    for (int i = tid; i < SS_H * (SS_T / 4); i += 256) {
+        const int ly = i / (SS_T / 4), lx = (i - ly * (SS_T / 4)) * 4;
+        float v[3][4];
 #pragma unroll
-        for (int k = 0; k < GS_SSIM_TAPS; ++k) {
-            const float g = ssim_tap(k);
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) v[c] += g * s_p[c][ly][lx + k];
+            for (int r = 0; r < 4; ++r) v[c][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < GS_SSIM_TAPS + 3; ++j) {
+            float in[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) in[c] = s_p[c][ly][lx + j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = j - r;
+                if (k >= 0 && k < GS_SSIM_TAPS) {
+                    const float g = ssim_tap(k);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c][r] += g * in[c];
+                }
+            }
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) s_x[c][ly][lx] = v[c];
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<float4*>(&s_x[c][ly][lx]) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
     }
     __syncthreads();
-    const int lx = tid & 31;
+    const int lx = tid & 31, ly0 = (tid >> 5) * 4;
+    float v[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[c][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < GS_SSIM_TAPS + 3; ++j) {
+        float in[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) in[c] = s_x[c][ly0 + j][lx];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = j - r;
+            if (k >= 0 && k < GS_SSIM_TAPS) {
+                const float g = ssim_tap(k);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[c][r] += g * in[c];
+            }
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int ly = (tid >> 5) + 8 * r;
-        float v[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < GS_SSIM_TAPS; ++k) {
-            const float g = ssim_tap(k);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) v[c] += g * s_x[c][ly + k][lx];
-        }
-        const int px = x0 + lx, py = y0 + ly;
+        const int px = x0 + lx, py = y0 + ly0 + r;
         if (px < W && py < H) {
             const size_t gi = plane + (size_t)py * W + px;
             float d = 0.0f;
-            d += v[0];
-            d += img1[gi] * 2.0f * v[1];
-            d += img2[gi] * v[2];
+            d += v[0][r];
+            d += img1[gi] * 2.0f * v[1][r];
+            d += img2[gi] * v[2][r];
             dL_dimg1[gi] = d;
         }
     }
