@@ -140,12 +140,13 @@ class KernelTimer:
         return out
 
 
-def algorithmic_bytes(kernel, P, visible, R, HW, passes):
+def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1):
     """Bytes one launch must move at least: per-unit figures times the units one
-    launch processes.  Preprocess and blend figures are those of the reference
-    data layout; the binning stages are counted in this implementation's layout
-    (8-byte (tile id, index) pairs, 2 passes over the tile bits), which is less
-    than the reference's 12-byte pairs and 6 passes would be."""
+    launch processes.  Preprocess and blend figures of the one-view kernels are
+    those of the reference data layout; the binning stages and the two batch
+    kernels (one launch for the V views of a step) are counted in this
+    implementation's own layout, which is less than V times the one-view
+    figure: that saving is what they are for."""
     return {
         "preprocess": 315.0 * visible + 20.0 * (P - visible),
         "depth_order": P * (16.0 + 8.0 + 4.0 + 4 * 16.0),       # bin read, pair write, histogram read, 4 passes
@@ -155,8 +156,12 @@ def algorithmic_bytes(kernel, P, visible, R, HW, passes):
         "render_fwd": 28.0 * R + 48.0 * HW,
         "render_bwd": 60.0 * R + 40.0 * HW + 56.0 * R,
         "preprocess_bwd": 575.0 * visible,
-        "preprocess_bwd_batch": 575.0 * visible,   # per view of the batch; bench scales it by the views per launch
-        "preprocess_batch": 315.0 * visible + 20.0 * (P - visible),   # likewise
+        # parameters (60 B) and SH row (192 B) read once; per view the 64-byte gradient record, radius and clamp
+        # flags in, the screen-space gradient (12 B) out; the 63 parameter gradients written once
+        "preprocess_bwd_batch": P * 60.0 + visible * 192.0 + V * (visible * 69.0 + P * 4.0 + P * 12.0) + P * 252.0,
+        # parameters and SH row read once; per view the 64-byte record, depth and clamp flags of the rendered
+        # Gaussians and radius, tile rectangle and statistics slot (28 B) of all of them out
+        "preprocess_batch": P * 60.0 + visible * 192.0 + V * (visible * 69.0 + P * 28.0),
     }.get(kernel)
 
 
@@ -426,11 +431,9 @@ def main():
         traffic = load_pmc_traffic(P, W, H)
         per_kernel = {}
         launches = lambda k: 1 if k in KernelTimer.PER_STEP else V          # per step
-        units = lambda k: V if k in KernelTimer.PER_STEP else 1             # views one launch works for
 
         def alg(k):
-            ab = algorithmic_bytes(k, P, visible, R, H * W, passes)
-            return ab * units(k) if ab else None
+            return algorithmic_bytes(k, P, visible, R, H * W, passes, V)
 
         for k, ms in kernels.items():
             ab = alg(k)

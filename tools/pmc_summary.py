@@ -20,15 +20,28 @@ KERNEL_KEYS = {  # kernel symbol substring -> bench.py kernel name
     "emit_keys_kernel": "emit_keys", "onesweep_kernel": "sort:onesweep", "sort_hist_kernel": "sort:hist",
     "sort_scan_hist_kernel": "sort:scan", "tile_ranges_kernel": "tile_ranges", "render_fwd_kernel": "render_fwd",
     "render_bwd_kernel": "render_bwd", "preprocess_bwd_kernel": "preprocess_bwd",
-    "preprocess_bwd_batch_kernel": "preprocess_bwd_batch", "order_gather_kernel": "depth_order:gather", "ssim_fwd": "ssim_fwd",
+    "preprocess_bwd_batch_kernel": "preprocess_bwd_batch", "preprocess_fwd_batch_kernel": "preprocess_batch", "order_gather_kernel": "depth_order:gather", "ssim_fwd": "ssim_fwd",
     "ssim_bwd": "ssim_bwd", "scan_blocks_kernel": "scan", "finish_gstat_kernel": "finish_stats"}
 
 
-def short(name):
+def short(name, grid=0):
+    """Logical kernel name; the two sorts (Gaussians by depth, instances by tile) run the same
+    kernels and are told apart by their grid size."""
     for k, v in KERNEL_KEYS.items():
         if k in name:
+            if v in ("sort:onesweep", "sort:hist"):
+                big = grid > (2_000_000 if v == "sort:onesweep" else 400_000)
+                return v if big else v.replace("sort:", "depth_order:")
             return v
     return None
+
+
+# bench.py kernel name -> (detail name, launches per view) that make it up
+COMPOSED = {
+    "sort": (("sort:hist", 1), ("sort:scan", 1), ("sort:onesweep", 2)),
+    "depth_order": (("depth_order:keys", 1), ("depth_order:hist", 1), ("depth_order:onesweep", 4)),
+    "emit_keys": (("depth_order:gather", 1), ("emit_keys", 1)),
+}
 
 
 def main():
@@ -42,7 +55,7 @@ def main():
     for path in newest.values():
         with open(path) as f:
             for row in csv.DictReader(f):
-                k = short(row["Kernel_Name"])
+                k = short(row["Kernel_Name"], int(row.get("Grid_Size") or 0))
                 if k:
                     acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
     counters = sorted({c for k in acc for c in acc[k]})
@@ -57,7 +70,6 @@ def main():
     print("wrote", out)
     # HBM traffic per launch, merged per bench kernel name (sub-kernels summed per logical step)
     traffic = defaultdict(float)
-    launches_per_step = {"sort:onesweep": 2, "sort:hist": 1, "sort:scan": 1}  # instance sort; the depth sort is listed apart
     for k in acc:
         fs = acc[k].get("FETCH_SIZE")
         ws = acc[k].get("WRITE_SIZE")
@@ -68,6 +80,9 @@ def main():
     with open(os.path.join(ROOT, "profiles", "pmc_traffic_detail.json"), "w") as f:
         json.dump({k: traffic[k] for k in sorted(traffic)}, f, indent=1)
     simple = {k: v for k, v in traffic.items() if ":" not in k}
+    for name, parts in COMPOSED.items():
+        if all(d in traffic for d, _ in parts if d != "sort:scan"):
+            simple[name] = sum(traffic.get(d, 0.0) * n for d, n in parts)
     out_d = {k: simple[k] for k in sorted(simple)}
     out_d["_workload"] = [6000000, 1920, 1080]   # bench.py defaults, which tools/collect_pmc.sh runs
     out_d["_note"] = "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB, mean over the launches of the PMC passes"
