@@ -8,9 +8,11 @@ street scene at 1920x1080 (SH degree 3, 4 `reps` channels, antialiasing on):
 activations -> rasterizer forward -> L1 + fused-ssim loss -> rasterizer
 backward.  A step is a batch of V views per GPU (default 8, different cameras)
 whose parameter gradients accumulate, followed with N > 1 by one RCCL sum
-all-reduce of the 63 floats per Gaussian.  Every rank holds a full replica and
-renders its own cameras: weak scaling, value = views per second over the
-whole job.  The step goes through `GaussianRasterizer.forward_params` (raw
+all-reduce of the 63 floats per Gaussian.  The forward preprocess and the
+per-Gaussian backward of the V views each run as one batch kernel per step, and
+the views in between are dealt to a few HIP streams (default 3) so that their
+kernels overlap.  Every rank holds a full replica and renders its own cameras:
+weak scaling, value = views per second over the whole job.  The step goes through `GaussianRasterizer.forward_params` (raw
 parameters; activations, SH concatenation and gradient accumulation inside the
 kernels); with N = 1 the same iteration through the unchanged reference
 signature (torch activations + torch.cat in front of `forward`) is timed too
@@ -219,6 +221,9 @@ def main():
                     help="params: forward_params (raw parameters); reference: unchanged reference signature")
     ap.add_argument("--no-batch-forward", action="store_true",
                     help="run the forward preprocess per view instead of once per step for all its views")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the views of a step are dealt to round-robin (kernels of different views overlap); "
+                         "1 = one view after the other")
     ap.add_argument("--no-defer", action="store_true",
                     help="run the per-Gaussian backward after every view instead of once per step for all its views")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -274,9 +279,11 @@ def main():
         return out
 
     reducer_ms = []
+    side_streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else []
     batch_fwd = use_params and not args.no_batch_forward and V > 1
 
-    def step(k=None, timer=None):
+    def step(k=None, timer=None, overlap=True):
+        side = side_streams if overlap else []
         if use_params:
             sink.begin_step()
         else:
@@ -287,10 +294,22 @@ def main():
             if timer is not None:
                 timer.arm(k * V)
             sink.prepare_views([rs for rs, _ in views])   # the forward preprocess of all V views, once
+        if len(side) > 1:
+            ready = torch.cuda.Event()
+            ready.record()
+            for st in side:
+                st.wait_event(ready)
         for v, (rs, gt) in enumerate(views):
             if timer is not None:
                 timer.arm(k * V + v)
-            out = one_view(rs, gt)
+            if len(side) > 1:
+                with torch.cuda.stream(side[v % len(side)]):
+                    out = one_view(rs, gt)
+            else:
+                out = one_view(rs, gt)
+        if len(side) > 1:
+            for st in side:
+                torch.cuda.current_stream().wait_stream(st)
         if use_params and not args.fwd_only:
             sink.flush()   # deferred mode: the per-Gaussian backward of all V views, once
         if world > 1 and not args.fwd_only:
@@ -332,10 +351,36 @@ def main():
         dt = float(tmax.item())
 
     deferred = use_params and sink.defer and not args.fwd_only
-    kernels = timer.means_ms(args.fwd_only, [k * V + V - 1 for k in range(args.steps)] if deferred else None,
-                             [k * V for k in range(args.steps)] if batch_fwd else None)
-    if batch_fwd:
-        kernels.pop("preprocess")   # that slot is empty when the views were preprocessed together
+
+    def kernel_means(tm, nsteps):
+        km = tm.means_ms(args.fwd_only, [k * V + V - 1 for k in range(nsteps)] if deferred else None,
+                         [k * V for k in range(nsteps)] if batch_fwd else None)
+        if batch_fwd:   # these slots are empty when the views were preprocessed (and their prefix sums run) together
+            for k in ("preprocess", "scan", "host_sync_gap"):
+                km.pop(k)
+        return km
+
+    # Per-kernel durations.  With the views on several streams the kernels of different views overlap in the
+    # timed region and an event pair there spans other views' kernels too: those numbers are kept
+    # (`kernels_in_timed_region_ms`), and the durations that the roofline figures use are measured, live and on
+    # the same workload, in a pass with one view after the other that follows the timed region.
+    overlapping = len(side_streams) > 1
+    kernels_overlapped, one_stream_it_s = None, None
+    if overlapping:
+        kernels_overlapped = kernel_means(timer, args.steps)
+        iso_steps = min(args.steps, 5)
+        timer = KernelTimer(iso_steps * V)
+        step(0, timer, overlap=False)
+        sync()
+        t1 = time.perf_counter()
+        for k in range(iso_steps):
+            step(k, timer, overlap=False)
+        sync()
+        one_stream_it_s = world * V * iso_steps / (time.perf_counter() - t1)
+        timer.arm(None)
+        kernels = kernel_means(timer, iso_steps)
+    else:
+        kernels = kernel_means(timer, args.steps)
     if deferred:
         kernels["means2d_grad"] = kernels.pop("preprocess_bwd")   # in deferred mode that slot times the gradient copy
     gx, gy = (W + 15) // 16, (H + 15) // 16
@@ -463,6 +508,7 @@ def main():
                                    (", forward only" if args.fwd_only else ", each fwd + fused-ssim loss + bwd, then one "
                                     "gradient all-reduce when n_gpus > 1; no optimizer"),
                        "api": "forward_params (raw parameters)" if use_params else "reference signature",
+                       "streams": max(1, len(side_streams)),
                        "gaussians": P, "views_per_gpu_per_step": V, "visible_mean": visible, "num_rendered_mean": R,
                        "pairs_tested_mean": pairs, "tile_list_mean": R / (gx * gy),
                        "image": [W, H], "parallelism": f"view-sharded x{world}, full replicas" if world > 1 else "single GPU",
@@ -472,11 +518,16 @@ def main():
                          "algorithmic_bytes_per_launch": ab, "ms_per_launch": kernels[dom],
                          "limited_by": BOUND.get(dom)},
             "kernels": per_kernel,
+            "kernels_measured_in": ("a pass with one view after the other, after the timed region (same process, same "
+                                    "workload)" if overlapping else "the timed region"),
             # the reference's sort (R pairs of u64 key + u32 value) is done here by the depth ordering of the
             # Gaussians plus the sort of the instances on their tile id: payload rate over both
             "sort_GBps": (R * 12.0 / ((kernels["sort"] + kernels["depth_order"]) * 1e-3) / 1e9) if R else None,
             "sort_hbm_GBps": (R * (4.0 + passes * 16.0) / (kernels["sort"] * 1e-3) / 1e9) if R else None,
         }
+        if overlapping:
+            res["kernels_in_timed_region_ms"] = kernels_overlapped
+            res["one_stream_it_s"] = one_stream_it_s
         res.update(extras)
         if world > 1 and reducer_ms:
             ms = float(np.mean([a.elapsed_time(b) for a, b in reducer_ms]))

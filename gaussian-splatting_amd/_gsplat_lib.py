@@ -48,7 +48,7 @@ class GsrBackwardView(C.Structure):
 class GsrForwardView(C.Structure):
     _fields_ = [("viewmatrix", _vp), ("projmatrix", _vp), ("campos", _vp), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
                 ("W", C.c_int), ("H", C.c_int), ("antialiasing", C.c_int), ("radii", _vp), ("out_depths", _vp),
-                ("geom_buffer", _vp), ("geom_bytes", C.c_size_t)]
+                ("geom_buffer", _vp), ("geom_bytes", C.c_size_t), ("num_rendered", C.c_int64), ("num_visible", C.c_int64)]
 
 
 class GsrLayout(C.Structure):

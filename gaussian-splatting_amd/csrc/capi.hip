@@ -229,7 +229,7 @@ int gsr_backward_geometry_batch(const GsrScene* s, int nviews, const GsrBackward
     return GSR_OK;
 }
 
-int gsr_preprocess_batch(const GsrScene* s, int nviews, const GsrForwardView* views, void* stream) {
+int gsr_preprocess_batch(const GsrScene* s, int nviews, GsrForwardView* views, void* stream) {
     if (!s || nviews < 0 || (nviews > 0 && !views)) return GSR_ERR_ARG;
     if (s->P < 0) return GSR_ERR_ARG;
     if (s->DIM != 0 && s->DIM != 4) return GSR_ERR_DIM;
@@ -238,7 +238,8 @@ int gsr_preprocess_batch(const GsrScene* s, int nviews, const GsrForwardView* vi
     if (s->M != 16 || s->D < 0 || s->D > 3 || s->cov3D_precomp || s->colors_precomp) return GSR_ERR_ARG;
     if (s->DIM > 0 && !s->reps) return GSR_ERR_ARG;
     for (int v = 0; v < nviews; ++v) {
-        const GsrForwardView& fv = views[v];
+        GsrForwardView& fv = views[v];
+        fv.num_rendered = fv.num_visible = 0;
         if (!fv.viewmatrix || !fv.projmatrix || !fv.campos || !fv.radii || !fv.out_depths || !fv.geom_buffer ||
             fv.W <= 0 || fv.H <= 0 || fv.W > 65535 * TILE_X || fv.H > 65535 * TILE_Y)
             return GSR_ERR_ARG;
@@ -249,6 +250,24 @@ int gsr_preprocess_batch(const GsrScene* s, int nviews, const GsrForwardView* vi
     mark(s, GSR_EV_FWD_BATCH_BEGIN, st);
     GSR_TRY(launch_preprocess_fwd_batch(*s, nviews, views, st));
     mark(s, GSR_EV_FWD_BATCH, st);
+    // prefix sums of every view, then all the totals with one host block
+    constexpr int CHUNK = 16;
+    for (int v0 = 0; v0 < nviews; v0 += CHUNK) {
+        const int n = nviews - v0 < CHUNK ? nviews - v0 : CHUNK;
+        uint64_t tot[CHUNK][3];
+        for (int k = 0; k < n; ++k) {
+            const GeomBuf g = geom_buf(views[v0 + k].geom_buffer, (size_t)s->P);
+            GSR_TRY(launch_scan_blocks(g, (s->P + PRE_BLOCK - 1) / PRE_BLOCK, st));
+            if (hipMemcpyAsync(tot[k], g.total, sizeof(tot[k]), hipMemcpyDeviceToHost, st) != hipSuccess)
+                return GSR_ERR_HIP;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) return GSR_ERR_HIP;
+        for (int k = 0; k < n; ++k) {
+            if (tot[k][1]) return GSR_ERR_OVERFLOW;
+            views[v0 + k].num_rendered = (int64_t)tot[k][0];
+            views[v0 + k].num_visible = (int64_t)tot[k][2];
+        }
+    }
     return GSR_OK;
 }
 

@@ -98,9 +98,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         o.image_buffer, o.image_bytes = ptr(img), img.numel()
         o.preprocessed = 1 if prepared else 0
         st = stream_of(dev)
-        R = C.c_int64(0)
-        check(L.gsr_forward_stage1(C.byref(s), C.byref(o), st, C.byref(R)), "rasterize_gaussians (stage 1)")
-        R = int(R.value)
+        if prepared and "num_rendered" in prepared:   # the batch call has run the prefix sums too
+            R = int(prepared["num_rendered"])
+            o.num_visible = int(prepared["num_visible"])
+        else:
+            R = C.c_int64(0)
+            check(L.gsr_forward_stage1(C.byref(s), C.byref(o), st, C.byref(R)), "rasterize_gaussians (stage 1)")
+            R = int(R.value)
         binning = torch.empty((L.gsr_binning_bytes(R) if R > 0 else 0,), **u8)
         check(L.gsr_forward_stage2(C.byref(s), C.byref(o), R, ptr(binning), binning.numel(), st),
               "rasterize_gaussians (stage 2)")
@@ -298,6 +302,8 @@ def preprocess_batch(means3D, opacities, scales, rotations, scale_modifier, sh, 
             out.append(d)
         if P != 0:
             check(L.gsr_preprocess_batch(C.byref(s), len(views), arr, stream_of(dev)), "preprocess_batch")
+        for k, d in enumerate(out):
+            d["num_rendered"], d["num_visible"] = int(arr[k].num_rendered), int(arr[k].num_visible)
     return out
 
 

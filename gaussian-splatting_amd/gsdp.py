@@ -70,6 +70,40 @@ def reduce_densify_stats(xyz_gradient_accum, denom, max_radii2D, group=None):
         w.wait()
 
 
+def run_views(sink, settings_list, loss_of_view, streams=()):
+    """The local views of one step through a `ParamGradSink` (raw-parameter rasterizer path):
+    `begin_step`, the forward preprocess of all the views in one pass, `loss_of_view(i, settings)`
+    (render view i with `forward_params(..., grad_sink=sink)` and return its scalar loss) and
+    `backward()` per view, then `flush()`.  With `streams` (a list of `torch.cuda.Stream`) the
+    views are dealt to them round-robin: the views are independent until the flush, and the
+    kernels of a view leave much of the GPU idle (sort passes that wait on their look-back, the
+    ramp-down of the blend kernels), so two or three views in flight finish sooner than one after
+    the other.  Gradients are the same sums either way (float atomics: not bit for bit).
+    Returns the detached losses."""
+    sink.begin_step()
+    sink.prepare_views(settings_list)
+    main = torch.cuda.current_stream()
+    if streams:
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for st in streams:
+            st.wait_event(ready)
+    losses = []
+    for i, rs in enumerate(settings_list):
+        if streams:
+            with torch.cuda.stream(streams[i % len(streams)]):
+                loss = loss_of_view(i, rs)
+                loss.backward()
+        else:
+            loss = loss_of_view(i, rs)
+            loss.backward()
+        losses.append(loss.detach())
+    for st in streams:
+        main.wait_stream(st)
+    sink.flush()
+    return losses
+
+
 def view_sharded_step(params, views, loss_of_view, group=None):
     """One multi-view step.  `params`: leaf tensors (requires_grad); `views`: the
     whole batch (every rank passes the same list); `loss_of_view(view)` renders

@@ -208,10 +208,14 @@ int gsr_backward_geometry_batch(const GsrScene* scene, int nviews, const GsrBack
  * same parameters, e.g. the views of one optimiser step).  Each Gaussian's parameters and SH row are
  * read once for all the views; per view the call leaves in geom_buffer, radii and out_depths exactly
  * what the preprocess of gsr_forward_stage1 would (bit for bit), except the 3D covariance, which the
- * backward recomputes.  Afterwards run gsr_forward_stage1 / stage2 per view with
- * GsrForwardOut.preprocessed = 1 and the same three buffers.  Needs the SH tensors split
- * (scene->shs_rest), M == 16 and scales + rotations; the camera fields, W, H and antialiasing of
- * `scene` are ignored (each view brings its own). */
+ * backward recomputes.  It also runs the prefix sums of every view and, blocking the host once for
+ * all of them, returns each view's instance count in num_rendered / num_visible: the views can go
+ * straight to gsr_forward_stage2 (GsrForwardOut.preprocessed = 1, num_visible copied over, the same
+ * three buffers), so a step of V views blocks the host once instead of V times.
+ * (gsr_forward_stage1 with preprocessed = 1 is also allowed: it repeats the sums and the copy.)
+ * Needs the SH tensors split (scene->shs_rest), M == 16 and scales + rotations; the camera fields,
+ * W, H and antialiasing of `scene` are ignored (each view brings its own).  Returns
+ * GSR_ERR_OVERFLOW if a view has 2^30 instances or more. */
 typedef struct {
     const float* viewmatrix;   /* device [16] */
     const float* projmatrix;   /* device [16] */
@@ -223,8 +227,10 @@ typedef struct {
     float* out_depths;         /* device [P], out (written where radii > 0) */
     void* geom_buffer;         /* device, >= gsr_geom_bytes(P), out */
     size_t geom_bytes;
+    int64_t num_rendered;      /* out (host): (Gaussian, tile) instances of this view */
+    int64_t num_visible;       /* out (host): Gaussians of this view with at least one instance */
 } GsrForwardView;
-int gsr_preprocess_batch(const GsrScene* scene, int nviews, const GsrForwardView* views, void* stream);
+int gsr_preprocess_batch(const GsrScene* scene, int nviews, GsrForwardView* views, void* stream);
 
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
                      void* stream);
