@@ -114,6 +114,12 @@ def lib():
     L.gso_adam_update.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int] + [C.c_double] * 6 + [_vp]
     L.gso_densify_stats.restype = C.c_int
     L.gso_densify_stats.argtypes = [C.c_int] + [_vp] * 6
+    L.gso_compact_temp_bytes.restype = C.c_size_t
+    L.gso_compact_temp_bytes.argtypes = [C.c_int64]
+    L.gso_compact_map.restype = C.c_int
+    L.gso_compact_map.argtypes = [C.c_int64, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_int64), _vp]
+    L.gso_gather_rows.restype = C.c_int
+    L.gso_gather_rows.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int, _vp]
     L.gsr_status_string.restype = C.c_char_p
     L.gsr_status_string.argtypes = [C.c_int]
     _lib = L
@@ -124,7 +130,8 @@ EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backw
             "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_backward_blend",
             "gsr_backward_geometry_batch", "gsr_preprocess_batch", "gsr_mark_visible", "gsr_sort_temp_bytes",
             "gsr_sort_pairs_u64_u32", "gsr_layout", "gsr_sorted_keys_u64", "gsk_dist2_temp_bytes", "gsk_dist2", "gss_ssim_forward",
-            "gss_ssim_backward", "gso_adam_update", "gso_densify_stats", "gsr_status_string")
+            "gss_ssim_backward", "gso_adam_update", "gso_densify_stats", "gso_compact_temp_bytes", "gso_compact_map",
+            "gso_gather_rows", "gsr_status_string")
 
 
 NUM_PROFILE_EVENTS = 18

@@ -382,6 +382,34 @@ int gso_densify_stats(int P, const int* radii, const float* dL_dmeans2D, float* 
                                            (hipStream_t)stream));
 }
 
+size_t gso_compact_temp_bytes(int64_t N) { return compact_temp_bytes(N > 0 ? N : 1); }
+
+int gso_compact_map(int64_t N, const uint8_t* keep, uint32_t* src_of_dst, void* temp, size_t temp_bytes, int64_t* kept,
+                    void* stream) {
+    if (N < 0 || !kept) return GSR_ERR_ARG;
+    *kept = 0;
+    if (N == 0) return GSR_OK;
+    if (N >= (1ll << 31)) return GSR_ERR_OVERFLOW;
+    if (!keep || !src_of_dst || !temp) return GSR_ERR_ARG;
+    if (temp_bytes < compact_temp_bytes(N)) return GSR_ERR_BUFFER;
+    hipStream_t st = (hipStream_t)stream;
+    uint64_t* total_dev = nullptr;
+    if (launch_compact_map(N, keep, src_of_dst, temp, st, &total_dev) != hipSuccess) return GSR_ERR_HIP;
+    uint64_t tot[2] = {0, 0};
+    if (hipMemcpyAsync(tot, total_dev, sizeof(tot), hipMemcpyDeviceToHost, st) != hipSuccess) return GSR_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return GSR_ERR_HIP;
+    *kept = (int64_t)tot[0];
+    return GSR_OK;
+}
+
+int gso_gather_rows(const void* src, void* dst, const uint32_t* src_of_dst, int64_t K, int M, void* stream) {
+    if (K < 0 || M <= 0) return GSR_ERR_ARG;
+    if (K == 0) return GSR_OK;
+    if (!src || !dst || !src_of_dst) return GSR_ERR_ARG;
+    if (K * (int64_t)M >= (1ll << 40)) return GSR_ERR_OVERFLOW;
+    return hip_status(launch_gather_rows(src, dst, src_of_dst, K, M, (hipStream_t)stream));
+}
+
 const char* gsr_status_string(int status) {
     switch (status) {
         case GSR_OK: return "ok";

@@ -514,6 +514,12 @@ hipError_t launch_scan_blocks(const GeomBuf& g, int nb, hipStream_t st) {
     return hipGetLastError();
 }
 
+// In-place exclusive scan of sums[0..nb) (sums[nb] = total), total[0] = total, total[1] = overflow flag.
+hipError_t launch_scan_u32(uint32_t* sums, int nb, uint64_t* total, hipStream_t st) {
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, sums, (uint32_t*)nullptr, nb, total);
+    return hipGetLastError();
+}
+
 hipError_t launch_depth_order(const GeomBuf& g, int P, int n, hipStream_t st, int* order_buffer) {
     hipLaunchKernelGGL(depth_keys_kernel, dim3((P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, st, P, g.bin,
                        n < P ? g.vis_sums : (const uint32_t*)nullptr, g.dkeys[0], g.dvals[0]);

@@ -107,6 +107,13 @@ hipError_t launch_adam(float* param, const float* grad, float* exp_avg, float* e
 hipError_t launch_densify_stats(int P, const int* radii, const float* dL_dmeans2D, float* xyz_gradient_accum,
                                 float* denom, float* max_radii2D, hipStream_t st);
 
+hipError_t launch_scan_u32(uint32_t* sums, int nb, uint64_t* total, hipStream_t st);
+size_t compact_temp_bytes(int64_t N);
+hipError_t launch_compact_map(int64_t N, const uint8_t* keep, uint32_t* src_of_dst, void* temp, hipStream_t st,
+                              uint64_t** total_dev);
+hipError_t launch_gather_rows(const void* src, void* dst, const uint32_t* src_of_dst, int64_t K, int M,
+                              hipStream_t st);
+
 hipError_t launch_knn(int P, const float* points, float* out, void* temp, hipStream_t st);
 size_t knn_temp_bytes(int P);
 

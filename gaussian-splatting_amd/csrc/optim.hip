@@ -88,4 +88,77 @@ hipError_t launch_densify_stats(int P, const int* radii, const float* dL_dmeans2
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ row compaction
+// Pruning (scene/gaussian_model.py:402-441) keeps the rows of a mask in seven
+// parameter tensors, their fourteen Adam moment tensors and four statistics
+// tensors; the reference does it with boolean indexing, i.e. one nonzero()
+// (a host block) and one gather per tensor.  Here the mask is turned once into
+// the list of kept row indices (ascending, as boolean indexing orders them),
+// the host learns the count with one copy, and every tensor is gathered with
+// that list.
+__global__ void __launch_bounds__(256) compact_count_kernel(int64_t N, const uint8_t* __restrict__ keep,
+                                                            uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t s_w[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t m = __ballot(i < N && keep[i] != 0);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ void __launch_bounds__(256) compact_map_kernel(int64_t N, const uint8_t* __restrict__ keep,
+                                                          const uint32_t* __restrict__ block_offsets,
+                                                          uint32_t* __restrict__ src_of_dst) {
+    __shared__ uint32_t s_w[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool k = i < N && keep[i] != 0;
+    const uint64_t m = __ballot(k);
+    if (lane == 0) s_w[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t base = block_offsets[blockIdx.x];
+    for (int j = 0; j < w; ++j) base += s_w[j];
+    if (k) src_of_dst[base + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = (uint32_t)i;
+}
+
+// dst[r, :] = src[src_of_dst[r], :], rows of M floats; one thread per 4 bytes, consecutive threads
+// walk a destination row.
+__global__ void __launch_bounds__(256) gather_rows_kernel(const uint32_t* __restrict__ src,
+                                                          uint32_t* __restrict__ dst,
+                                                          const uint32_t* __restrict__ src_of_dst, int64_t total,
+                                                          int M) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int64_t r = i / M;
+    const int c = (int)(i - r * M);
+    dst[i] = src[(int64_t)src_of_dst[r] * M + c];
+}
+
+size_t compact_temp_bytes(int64_t N) {
+    const size_t nb = (size_t)((N + 255) / 256);
+    return align_up((nb + 1) * sizeof(uint32_t), 256) + 4 * sizeof(uint64_t);
+}
+
+hipError_t launch_compact_map(int64_t N, const uint8_t* keep, uint32_t* src_of_dst, void* temp, hipStream_t st,
+                              uint64_t** total_dev) {
+    const int nb = (int)((N + 255) / 256);
+    uint32_t* block_sums = (uint32_t*)temp;
+    uint64_t* total = (uint64_t*)((char*)temp + align_up(((size_t)nb + 1) * sizeof(uint32_t), 256));
+    *total_dev = total;
+    hipLaunchKernelGGL(compact_count_kernel, dim3(nb), dim3(256), 0, st, N, keep, block_sums);
+    hipError_t e = launch_scan_u32(block_sums, nb, total, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(compact_map_kernel, dim3(nb), dim3(256), 0, st, N, keep, block_sums, src_of_dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(const void* src, void* dst, const uint32_t* src_of_dst, int64_t K, int M,
+                              hipStream_t st) {
+    const int64_t total = K * M;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const uint32_t*)src, (uint32_t*)dst, src_of_dst, total, M);
+    return hipGetLastError();
+}
+
 }  // namespace gs

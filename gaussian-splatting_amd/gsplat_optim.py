@@ -19,9 +19,11 @@ diff_gaussian_rasterization: the reference switches its renderer to a branch
 that does not work with the fork's rasterizer as soon as that import succeeds
 (train.py:38-42, gaussian_renderer/__init__.py:138-150).
 """
+import ctypes as C
 import math
 
 import torch
+import torch.nn as nn
 
 from _gsplat_lib import check, lib, stream_of
 
@@ -92,3 +94,82 @@ def add_densification_stats(radii, viewspace_grad, xyz_gradient_accum, denom, ma
         check(lib().gso_densify_stats(P, radii.data_ptr(), viewspace_grad.data_ptr(), xyz_gradient_accum.data_ptr(),
                                       denom.data_ptr(), max_radii2D.data_ptr(), stream_of(radii.device)),
               "densify stats")
+
+
+class RowCompactor:
+    """The kept rows of a boolean mask, computed once and applied to any number of tensors:
+    `RowCompactor(mask)(t)` equals `t[mask]` for tensors whose first dimension is the mask's
+    length.  One host block (to learn how many rows are kept) instead of one per tensor."""
+
+    def __init__(self, mask):
+        if mask.dim() != 1 or not mask.is_cuda:
+            raise RuntimeError("mask must be a 1-D GPU tensor (there is no CPU path)")
+        L = lib()
+        self.N = mask.shape[0]
+        self.device = mask.device
+        keep = (mask != 0).to(torch.uint8).contiguous() if mask.dtype not in (torch.uint8, torch.bool) else \
+            mask.contiguous().view(torch.uint8)
+        self.index = torch.empty((max(self.N, 1),), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            temp = torch.empty((L.gso_compact_temp_bytes(self.N),), dtype=torch.uint8, device=self.device)
+            kept = C.c_int64(0)
+            check(L.gso_compact_map(self.N, keep.data_ptr() if self.N else None, self.index.data_ptr(), temp.data_ptr(),
+                                    temp.numel(), C.byref(kept), stream_of(self.device)), "compact map")
+        self.kept = int(kept.value)
+
+    def __call__(self, t):
+        if t.shape[0] != self.N or t.device != self.device:
+            raise RuntimeError("tensor does not match the mask")
+        if t.element_size() != 4 or not t.is_contiguous():
+            return t[self.index[:self.kept].long()]   # other layouts: plain indexing with the same list
+        out = torch.empty((self.kept,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        M = t.numel() // max(self.N, 1)
+        if self.kept and M:
+            with torch.cuda.device(self.device):
+                check(lib().gso_gather_rows(t.data_ptr(), out.data_ptr(), self.index.data_ptr(), self.kept, M,
+                                            stream_of(self.device)), "gather rows")
+        return out
+
+
+@torch.no_grad()
+def prune_optimizer(optimizer, mask):
+    """GaussianModel._prune_optimizer (scene/gaussian_model.py:427-441) with the mask resolved once:
+    keeps the rows of `mask` in every group's parameter and in its Adam moments, re-registers the
+    state under the new nn.Parameter and returns {group name: new parameter}.  Also returns the
+    compactor as the second value, for the per-Gaussian statistics tensors that prune_points
+    filters next (scene/gaussian_model.py:419-424)."""
+    comp = RowCompactor(mask)
+    optimizable = {}
+    for group in optimizer.param_groups:
+        p = group["params"][0]
+        stored = optimizer.state.get(p, None)
+        new_p = nn.Parameter(comp(p.data).requires_grad_(True))
+        if stored is not None:
+            stored["exp_avg"] = comp(stored["exp_avg"])
+            stored["exp_avg_sq"] = comp(stored["exp_avg_sq"])
+            del optimizer.state[p]
+            optimizer.state[new_p] = stored
+        group["params"][0] = new_p
+        optimizable[group["name"]] = new_p
+    return optimizable, comp
+
+
+@torch.no_grad()
+def cat_tensors_to_optimizer(optimizer, tensors_dict):
+    """GaussianModel.cat_tensors_to_optimizer (scene/gaussian_model.py:325-346): appends the new
+    rows to every group's parameter, zero moments for them, returns {group name: new parameter}."""
+    optimizable = {}
+    for group in optimizer.param_groups:
+        assert len(group["params"]) == 1
+        ext = tensors_dict[group["name"]]
+        p = group["params"][0]
+        stored = optimizer.state.get(p, None)
+        new_p = nn.Parameter(torch.cat((p.data, ext), dim=0).requires_grad_(True))
+        if stored is not None:
+            stored["exp_avg"] = torch.cat((stored["exp_avg"], torch.zeros_like(ext)), dim=0)
+            stored["exp_avg_sq"] = torch.cat((stored["exp_avg_sq"], torch.zeros_like(ext)), dim=0)
+            del optimizer.state[p]
+            optimizer.state[new_p] = stored
+        group["params"][0] = new_p
+        optimizable[group["name"]] = new_p
+    return optimizable

@@ -290,6 +290,17 @@ int gso_adam_update(float* param, const float* grad, float* exp_avg, float* exp_
 int gso_densify_stats(int P, const int* radii, const float* dL_dmeans2D, float* xyz_gradient_accum, float* denom,
                       float* max_radii2D, void* stream);
 
+/* Row compaction for pruning (scene/gaussian_model.py:402-441, which keeps the rows of a mask in
+ * every parameter, Adam moment and statistics tensor by boolean indexing: one host-blocking
+ * nonzero() and one gather per tensor).  gso_compact_map turns the mask (device [N] bytes, nonzero =
+ * keep) into the ascending list of kept row indices src_of_dst (device [N] u32, the first *kept
+ * entries are valid) and blocks the host once to return the count; gso_gather_rows then copies
+ * dst[r, :] = src[src_of_dst[r], :] for rows of M 4-byte elements (any 4-byte type). */
+size_t gso_compact_temp_bytes(int64_t N);
+int gso_compact_map(int64_t N, const uint8_t* keep, uint32_t* src_of_dst, void* temp, size_t temp_bytes, int64_t* kept,
+                    void* stream);
+int gso_gather_rows(const void* src, void* dst, const uint32_t* src_of_dst, int64_t K, int M, void* stream);
+
 const char* gsr_status_string(int status);
 
 #ifdef __cplusplus

@@ -125,3 +125,65 @@ def test_densify_stats(oracle):
     mdn[vf] += 1
     assert torch.equal(mm, tm) and torch.equal(mdn, td)
     assert torch.allclose(ma, ta, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("N,frac", [(1, 1.0), (255, 0.5), (256, 0.0), (1000, 0.3), (70001, 0.9)])
+def test_row_compactor_equals_boolean_indexing(N, frac):
+    from gsplat_optim import RowCompactor
+    g = torch.Generator(device="cuda").manual_seed(N)
+    mask = torch.rand(N, device="cuda", generator=g) < frac
+    comp = RowCompactor(mask)
+    assert comp.kept == int(mask.sum())
+    for t in (torch.randn(N, 3, device="cuda"), torch.randn(N, 15, 3, device="cuda"), torch.randn(N, device="cuda"),
+              torch.randn(N, 1, device="cuda"), torch.arange(N, device="cuda", dtype=torch.int32),
+              torch.randn(N, 2, device="cuda", dtype=torch.float64)):
+        got = comp(t)
+        assert got.dtype == t.dtype and torch.equal(got, t[mask])
+
+
+def _adam_with_state(N, fused):
+    from gsplat_optim import FusedGaussianAdam
+    g = torch.Generator().manual_seed(5)
+    shapes = dict(xyz=(N, 3), f_dc=(N, 1, 3), f_rest=(N, 15, 3), opacity=(N, 1), scaling=(N, 3), rotation=(N, 4), reps=(N, 4))
+    groups = [{"params": [torch.nn.Parameter(torch.randn(*s, generator=g).cuda())], "lr": 1e-3, "name": n}
+              for n, s in shapes.items()]
+    opt = (FusedGaussianAdam if fused else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
+    for gr in opt.param_groups:
+        gr["params"][0].grad = torch.randn(*gr["params"][0].shape, generator=g).cuda()
+    opt.step()
+    return opt
+
+
+def test_prune_and_cat_match_the_reference_formulation():
+    """prune_optimizer / cat_tensors_to_optimizer against scene/gaussian_model.py:325-346, 427-441 restated."""
+    from gsplat_optim import cat_tensors_to_optimizer, prune_optimizer
+    N = 3001
+    a, b = _adam_with_state(N, True), _adam_with_state(N, True)
+    mask = torch.rand(N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) < 0.7
+    got, comp = prune_optimizer(a, mask)
+    for group in b.param_groups:   # the reference's loop
+        p = group["params"][0]
+        st = b.state.get(p)
+        st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"][mask], st["exp_avg_sq"][mask]
+        del b.state[p]
+        group["params"][0] = torch.nn.Parameter(p[mask].requires_grad_(True))
+        b.state[group["params"][0]] = st
+    for ga, gb in zip(a.param_groups, b.param_groups):
+        pa, pb = ga["params"][0], gb["params"][0]
+        assert got[ga["name"]] is pa and pa.requires_grad
+        assert torch.equal(pa, pb)
+        assert torch.equal(a.state[pa]["exp_avg"], b.state[pb]["exp_avg"])
+        assert torch.equal(a.state[pa]["exp_avg_sq"], b.state[pb]["exp_avg_sq"])
+    stats = torch.randn(N, 1, device="cuda")
+    assert torch.equal(comp(stats), stats[mask])
+    K = int(mask.sum())
+    ext = {g["name"]: torch.randn((17,) + tuple(g["params"][0].shape[1:]), device="cuda") for g in a.param_groups}
+    got = cat_tensors_to_optimizer(a, ext)
+    for g in a.param_groups:
+        p = g["params"][0]
+        assert got[g["name"]] is p and p.shape[0] == K + 17
+        assert torch.equal(p[K:], ext[g["name"]])
+        assert torch.count_nonzero(a.state[p]["exp_avg"][K:]) == 0 and a.state[p]["exp_avg"].shape == p.shape
+    for g in a.param_groups:   # the optimizer still steps after the surgery
+        g["params"][0].grad = torch.randn_like(g["params"][0])
+    a.step()

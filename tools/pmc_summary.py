@@ -96,10 +96,18 @@ def main():
         with open(path) as f, open(dst, "w") as g:
             g.write(f.read())
         print("wrote", dst)
-    j = os.path.join(SRC, "bench_under_rocprof.json")
-    if os.path.exists(j):
-        with open(j) as f, open(os.path.join(ROOT, "profiles", f"{tag}_bench_under_rocprof.json"), "w") as g:
+    stats = sorted(glob.glob(os.path.join(SRC, "trace_streams", "**", "*kernel_stats.csv"), recursive=True),
+                   key=os.path.getmtime)
+    for path in stats[-1:]:
+        dst = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats_streams.csv")
+        with open(path) as f, open(dst, "w") as g:
             g.write(f.read())
+        print("wrote", dst)
+    for name in ("bench_under_rocprof", "bench_under_rocprof_streams"):
+        j = os.path.join(SRC, name + ".json")
+        if os.path.exists(j):
+            with open(j) as f, open(os.path.join(ROOT, "profiles", f"{tag}_{name}.json"), "w") as g:
+                g.write(f.read())
 
 
 if __name__ == "__main__":
