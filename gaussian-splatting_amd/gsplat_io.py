@@ -132,3 +132,41 @@ def load_ply(path, max_sh_degree=None):
         rotation=rots,
         reps=np.stack([col(n) for n in rep_names], axis=1) if rep_names else None,
     )
+
+
+# ------------------------------------------------------------------ training checkpoints (.pth)
+# train.py:371-376 saves `torch.save((gaussians.capture(), iteration), path)` and train.py:77-80
+# loads it back into `gaussians.restore(model_params, opt)`.  The capture tuple of the fork has 13
+# entries (scene/gaussian_model.py:166-182); its order is restated here once so that a trainer built
+# on the raw-parameter path reads and writes files the reference's train.py can resume from.
+CAPTURE_FIELDS = ("active_sh_degree", "xyz", "reps", "features_dc", "features_rest", "scaling", "rotation", "opacity",
+                  "max_radii2D", "xyz_gradient_accum", "denom", "optimizer_state_dict", "spatial_lr_scale")
+
+
+def save_checkpoint(path, iteration, **fields):
+    """Writes the reference's checkpoint: ((13-tuple in CAPTURE_FIELDS order), iteration).
+    Pass every field by name; tensors are stored as given (nn.Parameter or plain, like capture())."""
+    import torch
+    missing = [k for k in CAPTURE_FIELDS if k not in fields]
+    extra = [k for k in fields if k not in CAPTURE_FIELDS]
+    if missing or extra:
+        raise ValueError(f"checkpoint fields: missing {missing}, unknown {extra}")
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save((tuple(fields[k] for k in CAPTURE_FIELDS), int(iteration)), path)
+
+
+def load_checkpoint(path, map_location=None):
+    """Reads a checkpoint written by the reference's train.py (or by save_checkpoint) into
+    ({field: value}, iteration).  Loaded with weights_only=True: tensors, nn.Parameter and plain
+    containers only, nothing in the file is executed."""
+    import torch
+    allow = getattr(torch.serialization, "safe_globals", None)
+    ctx = allow([torch.nn.Parameter]) if allow else None
+    if ctx is not None:
+        with ctx:
+            model_params, iteration = torch.load(path, map_location=map_location, weights_only=True)
+    else:
+        model_params, iteration = torch.load(path, map_location=map_location, weights_only=True)
+    if len(model_params) != len(CAPTURE_FIELDS):
+        raise ValueError(f"expected the fork's {len(CAPTURE_FIELDS)}-entry capture tuple, got {len(model_params)} entries")
+    return dict(zip(CAPTURE_FIELDS, model_params)), int(iteration)

@@ -75,3 +75,42 @@ def test_torch_tensors_and_ascii_file(tmp_path):
     r = gsplat_io.load_ply(os.path.join(tmp_path, "ascii.ply"), max_sh_degree=1)
     assert r["xyz"][1, 0] == table[1, order.index("x")] and r["features_rest"].shape == (2, 3, 3)
     assert r["features_rest"][0, 2, 1] == table[0, order.index("f_rest_5")]     # coefficient 2, channel 1 -> 1*3+2
+
+
+def test_checkpoint_round_trip_in_the_reference_layout(tmp_path):
+    """((capture 13-tuple), iteration) as train.py:371-376 writes it; restore order of
+    scene/gaussian_model.py:145-165."""
+    import torch
+    import gsplat_io
+    P = 37
+    g = torch.Generator().manual_seed(3)
+    params = dict(xyz=torch.nn.Parameter(torch.randn(P, 3, generator=g)), reps=torch.nn.Parameter(torch.randn(P, 4, generator=g)),
+                  features_dc=torch.nn.Parameter(torch.randn(P, 1, 3, generator=g)),
+                  features_rest=torch.nn.Parameter(torch.randn(P, 15, 3, generator=g)),
+                  scaling=torch.nn.Parameter(torch.randn(P, 3, generator=g)),
+                  rotation=torch.nn.Parameter(torch.randn(P, 4, generator=g)),
+                  opacity=torch.nn.Parameter(torch.randn(P, 1, generator=g)))
+    opt = torch.optim.Adam([{"params": [p], "lr": 1e-3, "name": n} for n, p in params.items()], lr=0.0, eps=1e-15)
+    for p in params.values():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    fields = dict(params, active_sh_degree=2, max_radii2D=torch.rand(P), xyz_gradient_accum=torch.rand(P, 1),
+                  denom=torch.rand(P, 1), optimizer_state_dict=opt.state_dict(), spatial_lr_scale=4.5)
+    path = str(tmp_path / "chkpnt7000.pth")
+    gsplat_io.save_checkpoint(path, 7000, **fields)
+    # what the reference's train.py does with the file
+    model_params, first_iter = torch.load(path, weights_only=False)
+    assert first_iter == 7000 and len(model_params) == 13
+    assert model_params[0] == 2 and model_params[12] == 4.5
+    assert torch.equal(model_params[1], params["xyz"]) and torch.equal(model_params[2], params["reps"])
+    assert torch.equal(model_params[7], params["opacity"]) and torch.equal(model_params[8], fields["max_radii2D"])
+    got, it = gsplat_io.load_checkpoint(path)
+    assert it == 7000 and set(got) == set(gsplat_io.CAPTURE_FIELDS)
+    for k in params:
+        assert torch.equal(got[k], params[k])
+    opt2 = torch.optim.Adam([{"params": [p], "lr": 1e-3, "name": n} for n, p in params.items()], lr=0.0, eps=1e-15)
+    opt2.load_state_dict(got["optimizer_state_dict"])
+    for p in params.values():
+        assert torch.equal(opt2.state[p]["exp_avg"], opt.state[p]["exp_avg"])
+    with pytest.raises(ValueError):
+        gsplat_io.save_checkpoint(path, 1, xyz=params["xyz"])
