@@ -147,6 +147,7 @@ onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* 
         uint64_t peers = __ballot(ok);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
+            if (b >= bits) break;  // a pass over fewer than 8 bits (the last one) has nothing to tell apart above them
             const bool bit = (d >> b) & 1;
             const uint64_t bal = __ballot(bit);
             peers &= bit ? bal : ~bal;
