@@ -3,6 +3,9 @@
   C2  2.5 M Gaussians, 1920x1080, render only      full comparison with the CPU checker
   C3  6 M Gaussians, 1297x840, antialiasing,        full comparison, forward and backward,
       forward + fused-ssim + backward               plus the ssim kernels on the rendered image
+  C4  6 M Gaussians, 1920x1080, 8 cameras,          the step as bench.py runs it (batched forward preprocess,
+      one multi-view step on one GPU                views on 3 streams, deferred backward) against the plain
+                                                    per-view path; one of the views in full against the CPU checker
   C5  20 M Gaussians, 3840x2160 render and          size-independent properties (sortedness, ranges,
       distCUDA2 over the 20 M points                permutation, counts), knn exact on a strided
                                                     sample of query points through the CPU checker
@@ -63,6 +66,68 @@ def test_c3_train_step_6M_1297x840(oracle):
         assert np.isfinite(got[k]).all(), k
         assert rel_err(got[k], r) <= REL_TOL, (k, rel_err(got[k], r))
     print(f"C3: R={f.R}, forward {t1 - t0:.1f}s, backward {t2 - t1:.1f}s")
+
+
+def test_c4_multi_view_step_6M_1080p(oracle):
+    import gsdp
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, ParamGradSink
+    P, W, H, V = 6_000_000, 1920, 1080, 8
+    sc = synth.street_scene(P, W, H, seed=2)
+    dev = "cuda:0"
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev)
+    op = np.clip(sc["opacities"], 1e-4, 1 - 1e-4)
+    raw = dict(xyz=sc["means3D"], features_dc=np.ascontiguousarray(sc["shs"][:, :1]),
+               features_rest=np.ascontiguousarray(sc["shs"][:, 1:]), opacity=np.log(op / (1 - op)).astype(np.float32),
+               scaling=np.log(sc["scales"]).astype(np.float32), rotation=sc["rotations"], reps=sc["reps"])
+    names = tuple(raw)
+    A = {n: t(raw[n]).requires_grad_(True) for n in names}
+    B = {n: t(raw[n]).requires_grad_(True) for n in names}
+    cams = [synth.street_camera(W, H, v, V) for v in range(V)]
+    settings = [GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], bg=torch.zeros(3, device=dev),
+        scale_modifier=1.0, viewmatrix=t(c["viewmatrix"]), projmatrix=t(c["projmatrix"]), sh_degree=sc["sh_degree"],
+        campos=t(c["campos"]), prefiltered=False, debug=False, antialiasing=True) for c in cams]
+    ws = [torch.randn((3, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(v)) for v in range(V)]
+    imgs = {}
+
+    def loss_of(P_, sink, tag):
+        def f(i, rs):
+            m2 = torch.zeros_like(P_["xyz"], requires_grad=True)
+            o = GaussianRasterizer(rs).forward_params(
+                P_["xyz"], m2, P_["features_dc"], P_["features_rest"], P_["opacity"], P_["scaling"], P_["rotation"],
+                P_["reps"], grad_sink=sink)
+            imgs[(tag, i)] = (o[0].detach(), o[1].detach(), o[4].detach())
+            return (o[0] * ws[i]).sum() / (H * W) + 0.01 * (o[5] - 10.0).abs().mean()
+        return f
+
+    # A: one view after the other, each with its own preprocess and per-Gaussian backward
+    sink_a = ParamGradSink(*[A[n] for n in names])
+    sink_a.begin_step()
+    for i, rs in enumerate(settings):
+        loss_of(A, sink_a, "a")(i, rs).backward()
+    # B: the batched step on three streams
+    sink_b = ParamGradSink(*[B[n] for n in names], defer=True)
+    gsdp.run_views(sink_b, settings, loss_of(B, sink_b, "b"), [torch.cuda.Stream() for _ in range(3)])
+    torch.cuda.synchronize()
+    for i in range(V):
+        for x, y in zip(imgs[("a", i)], imgs[("b", i)]):
+            assert torch.equal(x, y), i                      # image, radii, gauss_count: bit for bit
+    for n in names:
+        ga, gb = A[n].grad.cpu().numpy(), B[n].grad.cpu().numpy()
+        assert np.isfinite(gb).all(), n
+        assert rel_err(gb, ga) <= REL_TOL, (n, rel_err(gb, ga))
+    # one view of the batched step in full against the CPU checker
+    v = 5
+    o_, s_, r_ = oracle.activate(raw["opacity"].reshape(-1, 1), raw["scaling"], raw["rotation"])
+    sc2 = dict(sc)
+    sc2["opacities"], sc2["scales"], sc2["rotations"], sc2["camera"] = o_, s_, r_, cams[v]
+    t0 = time.time()
+    f = oracle.forward_from_scene(sc2, bg=(0.0, 0.0, 0.0), antialiasing=True)
+    print(f"C4: view {v}: R={f.R}, CPU checker forward {time.time() - t0:.1f}s")
+    img, radii, gcnt = imgs[("b", v)]
+    assert np.array_equal(radii.cpu().numpy(), f.radii)
+    assert np.array_equal(gcnt.cpu().numpy(), f.gauss_count)
+    assert np.abs(img.cpu().numpy() - f.out_color).max() <= ABS_TOL
 
 
 def test_c5_render_20M_4k_properties():
