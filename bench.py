@@ -442,6 +442,25 @@ def main():
             p.grad = g
         extras["render_fps"] = timed(fps_params, 20)
         extras["render_fps_reference_api"] = timed(fps_reference, 20)
+        if use_params:
+            def fps_batch():   # the V cameras of a step rendered as a batch: one preprocess pass, views on the side streams
+                with torch.no_grad():
+                    sink.begin_step()
+                    sink.prepare_views([rs for rs, _ in views])
+                    if side_streams:
+                        ready = torch.cuda.Event()
+                        ready.record()
+                        for st in side_streams:
+                            st.wait_event(ready)
+                    for v, (rs, _) in enumerate(views):
+                        if side_streams:
+                            with torch.cuda.stream(side_streams[v % len(side_streams)]):
+                                render_params(params, rs, sink)
+                        else:
+                            render_params(params, rs, sink)
+                    for st in side_streams:
+                        torch.cuda.current_stream().wait_stream(st)
+            extras["render_fps_batched"] = V * timed(fps_batch, 10)
 
         # optimizer step over the same 6 M x 63 floats (not part of `value`): fused Adam kernel, dense and on
         # the visible rows only, next to torch.optim.Adam as the reference configures it (gaussian_model.py:113)
