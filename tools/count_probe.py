@@ -1,5 +1,7 @@
 """Per-workgroup start / end timestamps of the two blend kernels from an instrumented build
-(GSPLAT_AMD_LIB=tools/lib_wgt.so, see the patch step in the development notes): how many
+(GSPLAT_AMD_LIB=tools/lib_wgt.so: a copy of csrc/ in which both kernels store wall_clock64() at entry and
+exit per workgroup into a __device__ array gs_wgt_f / gs_wgt_b and export it through gsr_dbg_wgt_f / _b,
+built with tools/build_variant_dir.sh): how many
 workgroups run concurrently over the kernel's life, how long the tail is, how the duration
 relates to the entries a tile walks.  Development tool, not part of the product."""
 import ctypes as C
