@@ -92,13 +92,18 @@ def render_params(params, rs, sink=None):
         params["rotation"], params["reps"], grad_sink=sink)
 
 
-def train_loss(out, gt, lambda_dssim=0.2, lambda_rep=0.01):
-    """train.py:222-251 without the depth prior: L1 + (1 - ssim) + rep regulariser."""
-    from fused_ssim import fused_ssim
-    image = out[0].clamp(0, 1)
-    l1 = torch.abs(image - gt).mean()
-    ssim_v = fused_ssim(image.unsqueeze(0), gt.unsqueeze(0))
-    loss = (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim_v)
+def train_loss(out, gt, lambda_dssim=0.2, lambda_rep=0.01, fused=False):
+    """train.py:222-251 without the depth prior: L1 + (1 - ssim) + rep regulariser.  fused: the photometric
+    part through fused_ssim.l1_ssim_loss (clamp, L1, ssim and their backward in three kernels); otherwise as
+    the reference composes it from PyTorch operations around fused_ssim."""
+    from fused_ssim import fused_ssim, l1_ssim_loss
+    if fused:
+        loss = l1_ssim_loss(out[0], gt, lambda_dssim)
+    else:
+        image = out[0].clamp(0, 1)
+        l1 = torch.abs(image - gt).mean()
+        ssim_v = fused_ssim(image.unsqueeze(0), gt.unsqueeze(0))
+        loss = (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim_v)
     return loss + lambda_rep * torch.abs(out[5] - 10.0).mean()
 
 
@@ -224,6 +229,9 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the views of a step are dealt to round-robin (kernels of different views overlap); "
                          "1 = one view after the other")
+    ap.add_argument("--torch-loss", action="store_true",
+                    help="compose the photometric loss from PyTorch operations around fused_ssim, as train.py does, "
+                         "instead of fused_ssim.l1_ssim_loss (the reference-signature runs always do)")
     ap.add_argument("--no-defer", action="store_true",
                     help="run the per-Gaussian backward after every view instead of once per step for all its views")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -267,6 +275,7 @@ def main():
         views.append((make_settings(cam, dev, sh_degree), gt))
     leaves = list(params.values())
     use_params = args.api == "params"
+    fused_loss = use_params and not args.torch_loss
     sink = ParamGradSink(*leaves, defer=not args.no_defer) if use_params else None
     log(f"[rank {rank}] scene ready in {time.time() - t0:.1f}s")
 
@@ -275,7 +284,7 @@ def main():
             with torch.no_grad():
                 return render_params(params, rs, sink) if use_params else render_reference_api(params, rs)
         out = render_params(params, rs, sink) if use_params else render_reference_api(params, rs)
-        train_loss(out, gt).backward()
+        train_loss(out, gt, fused=fused_loss).backward()
         return out
 
     reducer_ms = []
@@ -418,7 +427,7 @@ def main():
         def it_params():
             sink.begin_step() if use_params else None
             o = render_params(params, rs0, sink)
-            train_loss(o, gt0).backward()
+            train_loss(o, gt0, fused=fused_loss).backward()
             sink.flush()
 
         def it_reference():
@@ -528,6 +537,8 @@ def main():
                                     "gradient all-reduce when n_gpus > 1; no optimizer"),
                        "api": "forward_params (raw parameters)" if use_params else "reference signature",
                        "streams": max(1, len(side_streams)),
+                       "loss": ("fused_ssim.l1_ssim_loss + reps L1" if fused_loss else
+                                "PyTorch L1 / clamp around fused_ssim + reps L1 (as train.py)"),
                        "gaussians": P, "views_per_gpu_per_step": V, "visible_mean": visible, "num_rendered_mean": R,
                        "pairs_tested_mean": pairs, "tile_list_mean": R / (gx * gy),
                        "image": [W, H], "parallelism": f"view-sharded x{world}, full replicas" if world > 1 else "single GPU",

@@ -360,6 +360,30 @@ int gss_ssim_backward(int B, int CH, int H, int W, float C1, float C2, const flo
                                       (hipStream_t)stream));
 }
 
+size_t gss_loss_partial_floats(int planes, int H, int W) {
+    return (planes > 0 && H > 0 && W > 0) ? loss_partial_floats(planes, H, W) : 0;
+}
+
+int gss_l1_ssim_loss_forward(int planes, int H, int W, float C1, float C2, float lambda_dssim, const float* img,
+                             const float* gt, float* loss, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
+                             float* partial, void* stream) {
+    if (planes <= 0 || H <= 0 || W <= 0) return GSR_ERR_ARG;
+    if (!img || !gt || !loss || !partial) return GSR_ERR_ARG;
+    if (dm_dmu1 && (!dm_dsigma1_sq || !dm_dsigma12)) return GSR_ERR_ARG;
+    if (loss_partial_floats(planes, H, W) / 2 >= (1u << 30)) return GSR_ERR_OVERFLOW;
+    return hip_status(launch_loss_fwd(planes, H, W, C1, C2, lambda_dssim, img, gt, loss, dm_dmu1, dm_dsigma1_sq,
+                                      dm_dsigma12, partial, (hipStream_t)stream));
+}
+
+int gss_l1_ssim_loss_backward(int planes, int H, int W, float lambda_dssim, const float* grad_loss, const float* img,
+                              const float* gt, float* dL_dimg, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                              const float* dm_dsigma12, void* stream) {
+    if (planes <= 0 || H <= 0 || W <= 0) return GSR_ERR_ARG;
+    if (!grad_loss || !img || !gt || !dL_dimg || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12) return GSR_ERR_ARG;
+    return hip_status(launch_loss_bwd(planes, H, W, lambda_dssim, grad_loss, img, gt, dL_dimg, dm_dmu1, dm_dsigma1_sq,
+                                      dm_dsigma12, (hipStream_t)stream));
+}
+
 int gso_adam_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible,
                     int64_t N, int M, double lr, double beta1, double beta2, double eps, double bias_correction1,
                     double bias_correction2_sqrt, void* stream) {

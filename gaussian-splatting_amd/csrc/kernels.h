@@ -123,4 +123,12 @@ hipError_t launch_ssim_bwd(int B, int CH, int H, int W, const float* img1, const
                            float* dL_dimg1, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
                            hipStream_t st);
 
+size_t loss_partial_floats(int planes, int H, int W);
+hipError_t launch_loss_fwd(int planes, int H, int W, float C1, float C2, float lambda, const float* img,
+                           const float* gt, float* loss, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
+                           float* partial, hipStream_t st);
+hipError_t launch_loss_bwd(int planes, int H, int W, float lambda, const float* grad_loss, const float* img,
+                           const float* gt, float* dL_dimg, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                           const float* dm_dsigma12, hipStream_t st);
+
 }  // namespace gs

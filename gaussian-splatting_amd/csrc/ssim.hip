@@ -21,10 +21,17 @@ __device__ __forceinline__ float ssim_ld(const float* img, int y, int x, int H, 
     return (x >= 0 && x < W && y >= 0 && y < H) ? img[(size_t)y * W + x] : 0.0f;
 }
 
+// LOSS: the training loss of train.py:222-230 around the map.  img1 is the unclamped render: it is
+// clamped to [0, 1] on the way into LDS (gaussian_renderer/__init__.py:179); no map is stored, instead
+// the workgroup's sums of |img1 - img2| and of the map go to partial[2 * workgroup] (+1), in a fixed
+// order, for the finishing kernel.
+__device__ __forceinline__ float clamp01(float x) { return fmin_(fmax_(x, 0.0f), 1.0f); }
+
+template <bool LOSS>
 __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, float C1, float C2, const float* __restrict__ img1,
                                                        const float* __restrict__ img2, float* __restrict__ ssim_map,
                                                        float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
-                                                       float* __restrict__ dm_dsigma12) {
+                                                       float* __restrict__ dm_dsigma12, float* __restrict__ partial) {
     __shared__ float s_a[SS_H][SS_H + 1];
     __shared__ float s_b[SS_H][SS_H + 1];
     __shared__ __align__(16) float s_x[5][SS_H][SS_T];  // mu1, E[x^2], mu2, E[y^2], E[xy] after the horizontal pass
@@ -36,7 +43,8 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, float C1, f
 
     for (int i = tid; i < SS_H * SS_H; i += 256) {
         const int ly = i / SS_H, lx = i - ly * SS_H;
-        s_a[ly][lx] = ssim_ld(a, y0 + ly - 5, x0 + lx - 5, H, W);
+        const float va = ssim_ld(a, y0 + ly - 5, x0 + lx - 5, H, W);
+        s_a[ly][lx] = LOSS ? clamp01(va) : va;
         s_b[ly][lx] = ssim_ld(b, y0 + ly - 5, x0 + lx - 5, H, W);
     }
     __syncthreads();
@@ -90,13 +98,19 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, float C1, f
             }
         }
     }
+    float sum_l1 = 0.f, sum_m = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int px = x0 + lx, py = y0 + ly0 + r;
         if (px < W && py < H) {
             const SsimOut o = ssim_point(v[0][r], v[1][r], v[2][r], v[3][r], v[4][r], C1, C2);
             const size_t gi = plane + (size_t)py * W + px;
-            ssim_map[gi] = o.m;
+            if (LOSS) {
+                sum_m += o.m;
+                sum_l1 += fabsf(s_a[ly0 + r + 5][lx + 5] - s_b[ly0 + r + 5][lx + 5]);
+            } else {
+                ssim_map[gi] = o.m;
+            }
             if (dm_dmu1) {
                 dm_dmu1[gi] = o.dm_dmu1;
                 dm_dsigma1_sq[gi] = o.dm_dsigma1_sq;
@@ -104,14 +118,62 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, float C1, f
             }
         }
     }
+    if (LOSS) {
+        __shared__ float s_red[2][4];
+        const float w1 = wave_sum(sum_l1), wm = wave_sum(sum_m);
+        if ((tid & 63) == 0) {
+            s_red[0][tid >> 6] = w1;
+            s_red[1][tid >> 6] = wm;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            partial[2 * wg] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+            partial[2 * wg + 1] = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+        }
+    }
 }
 
+// loss[0] = (1 - lambda) * mean|img1 - img2| + lambda * (1 - mean(ssim map)), loss[1] = the L1 mean,
+// loss[2] = the ssim mean; one workgroup sums the partial sums in a fixed order (double accumulators).
+__global__ void __launch_bounds__(256) loss_finish_kernel(const float* __restrict__ partial, int n, double inv_count,
+                                                          float lambda, float* __restrict__ loss) {
+    __shared__ double s_r[2][256];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        a += (double)partial[2 * i];
+        b += (double)partial[2 * i + 1];
+    }
+    s_r[0][threadIdx.x] = a;
+    s_r[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            s_r[0][threadIdx.x] += s_r[0][threadIdx.x + off];
+            s_r[1][threadIdx.x] += s_r[1][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float l1 = (float)(s_r[0][0] * inv_count), m = (float)(s_r[1][0] * inv_count);
+        loss[0] = (1.0f - lambda) * l1 + lambda * (1.0f - m);
+        loss[1] = l1;
+        loss[2] = m;
+    }
+}
+
+// LOSS: backward of the loss above with respect to the unclamped img1.  dL/dmap is the same number
+// everywhere, -lambda / count times the incoming gradient of the loss (a device scalar: no host
+// block to read it), the L1 term adds (1 - lambda) / count * sign(clamp(img1) - img2), and the clamp
+// passes the gradient where 0 <= img1 <= 1.
+template <bool LOSS>
 __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, const float* __restrict__ img1,
                                                        const float* __restrict__ img2,
                                                        const float* __restrict__ dL_dmap, float* __restrict__ dL_dimg1,
                                                        const float* __restrict__ dm_dmu1,
                                                        const float* __restrict__ dm_dsigma1_sq,
-                                                       const float* __restrict__ dm_dsigma12) {
+                                                       const float* __restrict__ dm_dsigma12, float lambda,
+                                                       float inv_count) {
     __shared__ float s_p[3][SS_H][SS_H + 1];  // dL * (dm_dmu1, dm_dsigma1_sq, dm_dsigma12)
     __shared__ __align__(16) float s_x[3][SS_H][SS_T];
     const size_t plane = (size_t)blockIdx.z * H * W;
@@ -120,7 +182,7 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, const float
     for (int i = tid; i < SS_H * SS_H; i += 256) {
         const int ly = i / SS_H, lx = i - ly * SS_H;
         const int y = y0 + ly - 5, x = x0 + lx - 5;
-        const float dl = ssim_ld(dL_dmap + plane, y, x, H, W);
+        const float dl = LOSS ? (-lambda * inv_count) * dL_dmap[0] : ssim_ld(dL_dmap + plane, y, x, H, W);
         s_p[0][ly][lx] = ssim_ld(dm_dmu1 + plane, y, x, H, W) * dl;
         s_p[1][ly][lx] = ssim_ld(dm_dsigma1_sq + plane, y, x, H, W) * dl;
         s_p[2][ly][lx] = ssim_ld(dm_dsigma12 + plane, y, x, H, W) * dl;
@@ -179,10 +241,17 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, const float
         const int px = x0 + lx, py = y0 + ly0 + r;
         if (px < W && py < H) {
             const size_t gi = plane + (size_t)py * W + px;
+            const float raw = img1[gi], pb = img2[gi];
+            const float pa = LOSS ? clamp01(raw) : raw;
             float d = 0.0f;
             d += v[0][r];
-            d += img1[gi] * 2.0f * v[1][r];
-            d += img2[gi] * v[2][r];
+            d += pa * 2.0f * v[1][r];
+            d += pb * v[2][r];
+            if (LOSS) {
+                const float df = pa - pb;
+                d += ((1.0f - lambda) * inv_count) * dL_dmap[0] * (df > 0.f ? 1.0f : (df < 0.f ? -1.0f : 0.0f));
+                if (!(raw >= 0.0f && raw <= 1.0f)) d = 0.0f;
+            }
             dL_dimg1[gi] = d;
         }
     }
@@ -191,8 +260,8 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, const float
 hipError_t launch_ssim_fwd(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2,
                            float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, hipStream_t st) {
     const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, B * CH);
-    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, st, H, W, C1, C2, img1, img2, ssim_map, dm_dmu1,
-                       dm_dsigma1_sq, dm_dsigma12);
+    hipLaunchKernelGGL(ssim_fwd_kernel<false>, grid, dim3(256), 0, st, H, W, C1, C2, img1, img2, ssim_map, dm_dmu1,
+                       dm_dsigma1_sq, dm_dsigma12, (float*)nullptr);
     return hipGetLastError();
 }
 
@@ -200,8 +269,33 @@ hipError_t launch_ssim_bwd(int B, int CH, int H, int W, const float* img1, const
                            float* dL_dimg1, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
                            hipStream_t st) {
     const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, B * CH);
-    hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, st, H, W, img1, img2, dL_dmap, dL_dimg1, dm_dmu1,
-                       dm_dsigma1_sq, dm_dsigma12);
+    hipLaunchKernelGGL(ssim_bwd_kernel<false>, grid, dim3(256), 0, st, H, W, img1, img2, dL_dmap, dL_dimg1, dm_dmu1,
+                       dm_dsigma1_sq, dm_dsigma12, 0.0f, 0.0f);
+    return hipGetLastError();
+}
+
+size_t loss_partial_floats(int planes, int H, int W) {
+    return 2 * (size_t)((W + SS_T - 1) / SS_T) * ((H + SS_T - 1) / SS_T) * planes;
+}
+
+hipError_t launch_loss_fwd(int planes, int H, int W, float C1, float C2, float lambda, const float* img,
+                           const float* gt, float* loss, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
+                           float* partial, hipStream_t st) {
+    const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, planes);
+    hipLaunchKernelGGL(ssim_fwd_kernel<true>, grid, dim3(256), 0, st, H, W, C1, C2, img, gt, (float*)nullptr, dm_dmu1,
+                       dm_dsigma1_sq, dm_dsigma12, partial);
+    const int n = (int)(loss_partial_floats(planes, H, W) / 2);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, partial, n, 1.0 / ((double)planes * H * W), lambda,
+                       loss);
+    return hipGetLastError();
+}
+
+hipError_t launch_loss_bwd(int planes, int H, int W, float lambda, const float* grad_loss, const float* img,
+                           const float* gt, float* dL_dimg, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                           const float* dm_dsigma12, hipStream_t st) {
+    const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, planes);
+    hipLaunchKernelGGL(ssim_bwd_kernel<true>, grid, dim3(256), 0, st, H, W, img, gt, grad_loss, dL_dimg, dm_dmu1,
+                       dm_dsigma1_sq, dm_dsigma12, lambda, (float)(1.0 / ((double)planes * H * W)));
     return hipGetLastError();
 }
 

@@ -71,3 +71,51 @@ def fused_ssim(img1, img2, padding="same", train=True):
     C2 = 0.03 ** 2
     assert padding in allowed_padding
     return FusedSSIMMap.apply(C1, C2, img1, img2, padding, train).mean()
+
+
+class _L1SSIMLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, gt, lambda_dssim):
+        if not image.is_cuda:
+            raise RuntimeError("image must be a GPU tensor (there is no CPU path)")
+        dev = image.device
+        a, b = image.contiguous().float(), gt.contiguous().float()
+        if a.shape != b.shape or a.dim() < 2:
+            raise RuntimeError("image and gt must have the same shape [..., H, W]")
+        H, W = a.shape[-2], a.shape[-1]
+        planes = a.numel() // (H * W)
+        L = lib()
+        loss = torch.empty((3,), dtype=torch.float32, device=dev)
+        d1, d2, d3 = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+        partial = torch.empty((L.gss_loss_partial_floats(planes, H, W),), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.gss_l1_ssim_loss_forward(planes, H, W, 0.01 ** 2, 0.03 ** 2, float(lambda_dssim), ptr(a), ptr(b),
+                                             ptr(loss), ptr(d1), ptr(d2), ptr(d3), ptr(partial), stream_of(dev)),
+                  "l1_ssim_loss")
+        ctx.save_for_backward(a, b, d1, d2, d3)
+        ctx.lam, ctx.dims = float(lambda_dssim), (planes, H, W)
+        ctx.mark_non_differentiable(loss)
+        return loss[0], loss
+
+    @staticmethod
+    def backward(ctx, grad_loss, _parts):
+        a, b, d1, d2, d3 = ctx.saved_tensors
+        planes, H, W = ctx.dims
+        dev = a.device
+        g = grad_loss.contiguous().float()
+        out = torch.empty_like(a)
+        with torch.cuda.device(dev):
+            check(lib().gss_l1_ssim_loss_backward(planes, H, W, ctx.lam, ptr(g), ptr(a), ptr(b), ptr(out), ptr(d1),
+                                                  ptr(d2), ptr(d3), stream_of(dev)), "l1_ssim_loss backward")
+        return out, None, None
+
+
+def l1_ssim_loss(image, gt, lambda_dssim=0.2, return_parts=False):
+    """(1 - lambda_dssim) * l1_loss(c, gt) + lambda_dssim * (1 - fused_ssim(c, gt)) with
+    c = image.clamp(0, 1): the photometric loss of train.py:222-230 on the unclamped render
+    (gaussian_renderer/__init__.py:179 clamps it), forward in two kernels and backward in one
+    instead of fused-ssim plus a dozen elementwise PyTorch kernels.  No counterpart in the
+    reference's fused_ssim package.  `image`, `gt`: [C, H, W] or [B, C, H, W].  With
+    `return_parts` also returns a detached tensor (loss, L1 mean, ssim mean) for logging."""
+    loss, parts = _L1SSIMLoss.apply(image, gt, lambda_dssim)
+    return (loss, parts) if return_parts else loss

@@ -269,6 +269,22 @@ int gss_ssim_backward(int B, int CH, int H, int W, float C1, float C2, const flo
                       const float* dL_dmap, float* dL_dimg1, const float* dm_dmu1, const float* dm_dsigma1_sq,
                       const float* dm_dsigma12, void* stream);
 
+/* The photometric training loss in two kernels (train.py:222-230 computes it with a dozen PyTorch
+ * kernels around fused-ssim; gaussian_renderer/__init__.py:179 clamps the render before):
+ *   loss[0] = (1 - lambda_dssim) * mean|clamp(img, 0, 1) - gt| + lambda_dssim * (1 - mean ssim(clamp(img, 0, 1), gt))
+ *   loss[1] = the L1 mean, loss[2] = the ssim mean            (device [3])
+ * img and gt are device [planes, H, W] (planes = batch x channels), img the UNCLAMPED render.
+ * `partial` is scratch of gss_loss_partial_floats(planes, H, W) floats; the three derivative maps
+ * (device [planes, H, W] each) are kept for the backward, which returns dL/dimg for the incoming
+ * gradient *grad_loss of loss[0] (a device scalar, so the host never waits for it). */
+size_t gss_loss_partial_floats(int planes, int H, int W);
+int gss_l1_ssim_loss_forward(int planes, int H, int W, float C1, float C2, float lambda_dssim, const float* img,
+                             const float* gt, float* loss, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
+                             float* partial, void* stream);
+int gss_l1_ssim_loss_backward(int planes, int H, int W, float lambda_dssim, const float* grad_loss, const float* img,
+                              const float* gt, float* dL_dimg, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                              const float* dm_dsigma12, void* stream);
+
 /* Fused Adam step over one parameter tensor [N, M] (row = Gaussian), in place.
  * Replaces, for the model's parameter groups, torch.optim.Adam as configured at
  * scene/gaussian_model.py:112-113 (same operation order as its single-tensor path) and provides

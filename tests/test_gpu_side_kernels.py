@@ -104,3 +104,31 @@ def test_fused_ssim_value_and_grad(oracle, shape, padding):
     assert np.abs(ta.grad.cpu().numpy() - rg).max() <= 1e-6 * max(1e-3, np.abs(rg).max())
     m2, e1, _, _ = fusedssim(0.01 ** 2, 0.03 ** 2, ta.detach(), tb, False)
     assert e1.numel() == 0 and torch.equal(m2, m)
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 96), (3, 45, 75), (1, 3, 130, 131), (3, 1080, 1920)])
+@pytest.mark.parametrize("lam", [0.2, 0.0, 1.0])
+def test_l1_ssim_loss_equals_the_composed_formulation(shape, lam):
+    """fused_ssim.l1_ssim_loss against clamp + l1 + fused_ssim composed in PyTorch (train.py:222-230;
+    fused_ssim itself is pinned by the reference's conv2d SSIM fixture)."""
+    from fused_ssim import fused_ssim, l1_ssim_loss
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    img = (torch.rand(shape, device="cuda", generator=g) * 1.6 - 0.3)      # a fifth of the values get clamped
+    img.view(-1)[::97] = 0.0
+    img.view(-1)[5::89] = 1.0                                              # values on the clamp bounds pass the gradient
+    gt = torch.rand(shape, device="cuda", generator=g)
+    gt.view(-1)[7::101] = img.view(-1)[7::101].clamp(0, 1)                 # exact ties: sign(0) = 0
+    a = img.clone().requires_grad_(True)
+    c = a.clamp(0, 1)
+    c4, g4 = (c, gt) if c.dim() == 4 else (c.unsqueeze(0), gt.unsqueeze(0))
+    ref = (1.0 - lam) * (c - gt).abs().mean() + lam * (1.0 - fused_ssim(c4, g4))
+    (ref * 1.7).backward()
+    b = img.clone().requires_grad_(True)
+    got, parts = l1_ssim_loss(b, gt, lam, return_parts=True)
+    (got * 1.7).backward()
+    assert abs(float(got) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert abs(float(parts[1]) - float((c - gt).abs().mean())) <= 2e-6
+    assert float(parts[0]) == float(got)
+    scale = float(a.grad.abs().max())
+    assert float((b.grad - a.grad).abs().max()) <= 2e-6 * scale
+    assert torch.equal(b.grad == 0, a.grad == 0)
