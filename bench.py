@@ -483,6 +483,11 @@ def main():
             extras.setdefault("optimizer_step_ms", {})[name] = 1e3 / timed(lambda: fn(opt), 10)
             del opt
 
+        # simple-knn initialisation (scene/gaussian_model.py:533) over the scene's 6 M points
+        from simple_knn._C import distCUDA2
+        pts = params["xyz"].detach()
+        extras["dist2_ms"] = {"points": P, "ms": 1e3 / timed(lambda: distCUDA2(pts), 3)}
+
         # densification statistics after a view: the fused kernel next to the reference's formulation
         from gsplat_optim import add_densification_stats
         o = render_params(params, rs0)
