@@ -55,6 +55,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             rs.campos, rs.prefiltered, rs.antialiasing, rs.debug, reps)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.out_shapes = (color.shape, out_reps.shape)
+        # outputs the loss does not use arrive in backward as None instead of freshly zero-filled tensors:
+        # no fill kernels, and an unused inverse-depth output switches its gradient path off in the kernels
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
                               geomBuffer, binningBuffer, imgBuffer, reps)
         return color, radii, invdepths, gauss_sum, gauss_count, out_reps
@@ -64,6 +68,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities, geomBuffer, binningBuffer,
          imgBuffer, reps) = ctx.saved_tensors
+        grad_out_color, grad_out_depth, grad_out_reps = _given_grads(ctx, means3D, grad_out_color, grad_out_depth,
+                                                                     grad_out_reps)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_reps) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
@@ -77,6 +83,20 @@ class _RasterizeGaussians(torch.autograd.Function):
         return (grad_means3D, grad_means2D, given(sh, grad_sh), given(colors_precomp, grad_colors_precomp),
                 grad_opacities.view_as(opacities), given(scales, grad_scales), given(rotations, grad_rotations),
                 given(cov3Ds_precomp, grad_cov3Ds_precomp), None, given(reps, grad_reps))
+
+
+def _given_grads(ctx, like, grad_color, grad_depth, grad_reps):
+    """Incoming gradients with materialisation off: the colour gradient is needed by the kernels
+    (zeros if the loss did not use the image), the inverse-depth one is optional (None switches
+    that path off), the reps one is needed when there are reps channels."""
+    color_shape, reps_shape = ctx.out_shapes
+    if grad_color is None:
+        grad_color = torch.zeros(color_shape, dtype=torch.float32, device=like.device)
+    if grad_depth is None:
+        grad_depth = torch.Tensor([])
+    if grad_reps is None:
+        grad_reps = torch.zeros(reps_shape, dtype=torch.float32, device=like.device) if reps_shape[0] else torch.Tensor([])
+    return grad_color, grad_depth, grad_reps
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -191,6 +211,8 @@ class _RasterizeGaussiansParams(torch.autograd.Function):
             prepared=prepared)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.out_shapes = (color.shape, out_reps.shape)
+        ctx.set_materialize_grads(False)
         ctx.sink = sink
         ctx.means2D = means2D
         ctx.save_for_backward(xyz, scaling, rotation, radii, features_dc, features_rest, opacity, geomBuffer,
@@ -202,6 +224,8 @@ class _RasterizeGaussiansParams(torch.autograd.Function):
         rs = ctx.raster_settings
         (xyz, scaling, rotation, radii, features_dc, features_rest, opacity, geomBuffer, binningBuffer, imgBuffer,
          reps) = ctx.saved_tensors
+        grad_out_color, grad_out_depth, grad_out_reps = _given_grads(ctx, xyz, grad_out_color, grad_out_depth,
+                                                                     grad_out_reps)
         sink = ctx.sink
         empty = torch.Tensor([])
         if sink is not None and sink.defer:

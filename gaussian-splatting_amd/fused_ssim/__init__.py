@@ -95,11 +95,14 @@ class _L1SSIMLoss(torch.autograd.Function):
         ctx.save_for_backward(a, b, d1, d2, d3)
         ctx.lam, ctx.dims = float(lambda_dssim), (planes, H, W)
         ctx.mark_non_differentiable(loss)
+        ctx.set_materialize_grads(False)
         return loss[0], loss
 
     @staticmethod
     def backward(ctx, grad_loss, _parts):
         a, b, d1, d2, d3 = ctx.saved_tensors
+        if grad_loss is None:
+            return None, None, None
         planes, H, W = ctx.dims
         dev = a.device
         g = grad_loss.contiguous().float()
