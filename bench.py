@@ -86,7 +86,7 @@ def render_reference_api(params, rs):
 def render_params(params, rs, sink=None):
     """The same render from the raw parameters (activations and concatenation in the kernels)."""
     from diff_gaussian_rasterization import GaussianRasterizer
-    means2D = torch.zeros_like(params["xyz"], requires_grad=True)
+    means2D = torch.empty_like(params["xyz"], requires_grad=True)   # a gradient sink: its values are never read
     return GaussianRasterizer(rs).forward_params(
         params["xyz"], means2D, params["features_dc"], params["features_rest"], params["opacity"], params["scaling"],
         params["rotation"], params["reps"], grad_sink=sink)
