@@ -73,6 +73,28 @@ def test_argument_validation_without_gpu():
     assert L.gsr_sort_pairs_u64_u32(None, None, None, None, 10, 44, None, 0, None, C.byref(res)) == -1
     assert L.gsr_sort_pairs_u64_u32(None, None, None, None, 1 << 31, 44, None, 0, None, C.byref(res)) == -3
     assert b"reps" in L.gsr_status_string(-2)
+    # the batch entry points, the loss and the row compaction validate before touching a device too
+    from _gsplat_lib import GsrBackwardView, GsrForwardView
+    s.P = 10
+    fv = (GsrForwardView * 2)()
+    assert L.gsr_preprocess_batch(C.byref(s), 2, fv, None) == -1                       # null parameters
+    assert L.gsr_preprocess_batch(C.byref(s), 0, fv, None) == 0
+    assert L.gsr_preprocess_batch(C.byref(s), -1, fv, None) == -1
+    bv = (GsrBackwardView * 1)()
+    assert L.gsr_backward_geometry_batch(C.byref(s), 1, bv, C.byref(GsrBackwardIO()), None) == -1
+    assert L.gsr_backward_geometry_batch(C.byref(s), 0, bv, C.byref(GsrBackwardIO()), None) == 0
+    assert L.gss_loss_partial_floats(3, 1080, 1920) == 2 * 60 * 34 * 3
+    assert L.gss_l1_ssim_loss_forward(3, 8, 8, 1e-4, 9e-4, 0.2, None, None, None, None, None, None, None, None) == -1
+    assert L.gss_l1_ssim_loss_backward(3, 8, 8, 0.2, None, None, None, None, None, None, None, None) == -1
+    assert L.gss_l1_ssim_loss_forward(0, 8, 8, 1e-4, 9e-4, 0.2, None, None, None, None, None, None, None, None) == -1
+    kept = C.c_int64(5)
+    assert L.gso_compact_temp_bytes(1000) >= 4 * 5
+    assert L.gso_compact_map(0, None, None, None, 0, C.byref(kept), None) == 0 and kept.value == 0
+    assert L.gso_compact_map(10, None, None, None, 0, C.byref(kept), None) == -1
+    assert L.gso_compact_map(1 << 31, None, None, None, 0, C.byref(kept), None) == -3
+    assert L.gso_gather_rows(None, None, None, 0, 3, None) == 0
+    assert L.gso_gather_rows(None, None, None, 5, 3, None) == -1
+    assert L.gso_gather_rows(None, None, None, 5, 0, None) == -1
 
 
 def test_operator_layer_mirrors_reference_checks():
@@ -109,6 +131,11 @@ def test_operator_layer_mirrors_reference_checks():
         fused_ssim.fused_ssim(torch.zeros(1, 3, 16, 16), torch.zeros(1, 3, 16, 16))
     with pytest.raises(AssertionError):
         fused_ssim.fused_ssim(torch.zeros(1, 3, 16, 16), torch.zeros(1, 3, 16, 16), padding="full")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        fused_ssim.l1_ssim_loss(torch.zeros(3, 16, 16), torch.zeros(3, 16, 16))
+    from gsplat_optim import RowCompactor
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        RowCompactor(torch.ones(10, dtype=torch.bool))
 
 
 def test_product_never_touches_the_oracle():
