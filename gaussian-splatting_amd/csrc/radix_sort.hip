@@ -1,5 +1,6 @@
-// Stable LSD radix sort of (key, u32 value) pairs with u64 or u32 keys, 8 bits
-// per pass, one sweep over the data per pass ("onesweep"): digit histograms of
+// Stable LSD radix sort of (key, u32 value) pairs with u64 or u32 keys, at most
+// 8 bits per pass (the key bits are dealt evenly to the passes), one sweep over
+// the data per pass ("onesweep"): digit histograms of
 // all passes are taken in one upfront read (or handed in by the producer of the
 // keys); each pass then ranks a 4096-key tile in LDS, obtains its global digit
 // offsets by decoupled look-back over the preceding tiles' published counts,
@@ -24,6 +25,14 @@ constexpr int LOOK_BATCH = GS_LOOK_BATCH;
 
 int sort_passes_for(int begin_bit, int end_bit) { return (end_bit - begin_bit + 7) / 8; }
 
+// The key bits are dealt evenly to the passes (13 bits: 7 + 6, not 8 + 5): the fewer buckets a
+// pass has, the longer the contiguous run a tile writes into each of them.
+__host__ __device__ inline void digit_of_pass(int nbits, int passes, int p, int* shift, int* bits) {
+    const int base = nbits / passes, extra = nbits % passes;
+    *bits = base + (p < extra ? 1 : 0);
+    *shift = p * base + (p < extra ? p : extra);
+}
+
 template <class K>
 __global__ void __launch_bounds__(256) sort_hist_kernel(const K* keys, int64_t n, int passes, int begin_bit,
                                                         int end_bit, uint32_t* ghist) {
@@ -34,8 +43,9 @@ __global__ void __launch_bounds__(256) sort_hist_kernel(const K* keys, int64_t n
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const K k = keys[i];
         for (int p = 0; p < passes; ++p) {
-            const int bits = min(8, end_bit - begin_bit - 8 * p);
-            const uint32_t d = (uint32_t)(k >> (begin_bit + 8 * p)) & ((1u << bits) - 1);
+            int shift, bits;
+            digit_of_pass(end_bit - begin_bit, passes, p, &shift, &bits);
+            const uint32_t d = (uint32_t)(k >> (begin_bit + shift)) & ((1u << bits) - 1);
             atomicAdd(&h[p * 256 + d], 1u);
         }
     }
@@ -81,7 +91,7 @@ __device__ __forceinline__ uint32_t block_scan_excl_256_nw(uint32_t v, uint32_t*
 #ifndef GS_OS_BLOCKS
 #define GS_OS_BLOCKS 2
 #endif
-template <class K, int THREADS, int ITEMS>
+template <class K, int THREADS, int ITEMS, int BITS>
 __global__ void __launch_bounds__(THREADS, (GS_OS_BLOCKS * THREADS) / 256)
 onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __restrict__ kout,
                 uint32_t* __restrict__ vout, int64_t n, int shift, int bits, const uint32_t* __restrict__ gbase,
@@ -137,23 +147,30 @@ onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* 
     if (dthread) s_dstart[tid] = dstart;
 
     // 2. Stable ranking inside the wave: lanes holding the same digit find each
-    //    other with 8 ballots; the lowest such lane advances the wave's counter.
-    const uint64_t lt_mask = (1ull << lane) - 1;
-    volatile uint32_t* wh = s_whist + w * 256;
+    //    other with one ballot per digit bit; the lowest such lane advances the
+    //    wave's counter.  The peer mask is kept as two 32-bit halves: with the
+    //    digit bit sign-extended to m = 0 / ~0, "keep the lanes whose bit equals
+    //    mine" is peers &= ~(ballot ^ m), one three-input bit operation per half.
+    //    Bits above `bits` are zero in every digit and change nothing, so the
+    //    loop runs over the BITS the kernel was instantiated for without a test.
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
+    lds_u32* const wh = (lds_u32*)(s_whist + w * 256);
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
         const bool ok = (wave_base + k * 64 + lane) < n;
         const uint32_t d = (uint32_t)(key[k] >> shift) & dmask;
-        uint64_t peers = __ballot(ok);
+        const uint64_t okm = __builtin_amdgcn_ballot_w64(ok);
+        uint32_t plo = (uint32_t)okm, phi = (uint32_t)(okm >> 32);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            if (b >= bits) break;  // a pass over fewer than 8 bits (the last one) has nothing to tell apart above them
-            const bool bit = (d >> b) & 1;
-            const uint64_t bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
+        for (int b = 0; b < BITS; ++b) {
+            uint32_t m = (uint32_t)(((int32_t)(d << (31 - b))) >> 31);
+            asm("" : "+v"(m));  // the ballot compares m itself, not a second extraction of the bit
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(m != 0);
+            plo &= ~((uint32_t)bal ^ m);
+            phi &= ~((uint32_t)(bal >> 32) ^ m);
         }
-        const uint32_t lower = __popcll(peers & lt_mask);
-        const uint32_t cnt = __popcll(peers);
+        const uint32_t lower = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+        const uint32_t cnt = __popc(plo) + __popc(phi);
         const uint32_t prev = wh[d];
         if (ok && lower == 0) wh[d] = prev + cnt;
         rank[k] = prev + lower;
@@ -283,16 +300,19 @@ hipError_t radix_sort_impl(K* keys[2], uint32_t* vals[2], int64_t n, int begin_b
                            end_bit, t.ghist);
     }
     hipLaunchKernelGGL(sort_scan_hist_kernel, dim3(passes), dim3(256), 0, st, t.ghist);
-    auto kern = onesweep_kernel<K, OS_THREADS, OS_ITEMS>;
-    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)OS_LDS);
-    if (ea != hipSuccess) return ea;
     int cur = 0;
     for (int p = 0; p < passes; ++p) {
-        const int left_bits = end_bit - begin_bit - 8 * p;
-        const int bits = left_bits < 8 ? left_bits : 8;
+        int shift, bits;
+        digit_of_pass(end_bit - begin_bit, passes, p, &shift, &bits);
+        // u32 keys (the rasterizer's two sorts) have kernels for 6-, 7- and 8-bit digits
+        auto kern = onesweep_kernel<K, OS_THREADS, OS_ITEMS, 8>;
+        if (sizeof(K) == 4 && bits <= 6) kern = onesweep_kernel<K, OS_THREADS, OS_ITEMS, sizeof(K) == 4 ? 6 : 8>;
+        else if (sizeof(K) == 4 && bits == 7) kern = onesweep_kernel<K, OS_THREADS, OS_ITEMS, sizeof(K) == 4 ? 7 : 8>;
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)OS_LDS);
+        if (ea != hipSuccess) return ea;
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(OS_THREADS), OS_LDS, st, keys[cur], vals[cur],
-                           keys[cur ^ 1], vals[cur ^ 1], n, begin_bit + 8 * p, bits, t.ghist + p * 256,
+                           keys[cur ^ 1], vals[cur ^ 1], n, begin_bit + shift, bits, t.ghist + p * 256,
                            t.status + (size_t)p * tiles * 256, t.ticket + p, t.err);
         cur ^= 1;
     }

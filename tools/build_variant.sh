@@ -3,5 +3,5 @@
 set -e
 cd /root/repo/gaussian-splatting_amd/csrc
 d=/tmp/var_$1; mkdir -p $d
-for f in *.hip; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 $2 -c $f -o $d/${f%.hip}.o & done; wait
+for f in *.hip; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -std=c++17 $2 -c $f -o $d/${f%.hip}.o & done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o /root/repo/tools/lib_$1.so $d/*.o
