@@ -33,22 +33,47 @@ __host__ __device__ inline void digit_of_pass(int nbits, int passes, int p, int*
     *shift = p * base + (p < extra ? p : extra);
 }
 
+// Digit histograms of all passes in one read of the keys, 16 bytes per lane and load (a lane
+// that reads one key per trip spends its time waiting for that load).
 template <class K>
 __global__ void __launch_bounds__(256) sort_hist_kernel(const K* keys, int64_t n, int passes, int begin_bit,
                                                         int end_bit, uint32_t* ghist) {
+    constexpr int V = 16 / sizeof(K);
     __shared__ uint32_t h[SORT_MAX_PASSES * 256];
     for (int i = threadIdx.x; i < passes * 256; i += 256) h[i] = 0;
     __syncthreads();
+    int shift[SORT_MAX_PASSES], bits[SORT_MAX_PASSES];
+    for (int p = 0; p < passes; ++p) digit_of_pass(end_bit - begin_bit, passes, p, &shift[p], &bits[p]);
+    auto count = [&](K k) {
+        for (int p = 0; p < passes; ++p)
+            atomicAdd(&h[p * 256 + ((uint32_t)(k >> (begin_bit + shift[p])) & ((1u << bits[p]) - 1))], 1u);
+    };
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const K k = keys[i];
+    const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // whole 16-byte groups when the array starts on a 16-byte boundary, single keys otherwise and for the rest
+    const int64_t nvec = (reinterpret_cast<uintptr_t>(keys) & 15) == 0 ? n / V : 0;
+    struct alignas(16) Group { K k[V]; };
+    const Group* groups = reinterpret_cast<const Group*>(keys);
+    for (int64_t i = gtid; i < nvec; i += stride) {
+        const Group g = groups[i];
+        // neighbouring keys often share a digit (the tile ids of one splat row): one add per run
         for (int p = 0; p < passes; ++p) {
-            int shift, bits;
-            digit_of_pass(end_bit - begin_bit, passes, p, &shift, &bits);
-            const uint32_t d = (uint32_t)(k >> (begin_bit + shift)) & ((1u << bits) - 1);
-            atomicAdd(&h[p * 256 + d], 1u);
+            const uint32_t mask = (1u << bits[p]) - 1;
+            uint32_t cur = (uint32_t)(g.k[0] >> (begin_bit + shift[p])) & mask, c = 1;
+#pragma unroll
+            for (int e = 1; e < V; ++e) {
+                const uint32_t d = (uint32_t)(g.k[e] >> (begin_bit + shift[p])) & mask;
+                if (d != cur) {
+                    atomicAdd(&h[p * 256 + cur], c);
+                    cur = d;
+                    c = 0;
+                }
+                ++c;
+            }
+            atomicAdd(&h[p * 256 + cur], c);
         }
     }
+    for (int64_t i = nvec * V + gtid; i < n; i += stride) count(keys[i]);
     __syncthreads();
     for (int i = threadIdx.x; i < passes * 256; i += 256) {
         const uint32_t v = h[i];
