@@ -38,6 +38,7 @@ struct PreBwdArgs {
     const float* cov3D;  // the precomputed 3D covariance, if that is what the caller gave
     CamPtrs cam;
     const int* radii;
+    const float2* gstat;  // the forward's per-Gaussian (sum of T, pixels that reached it)
     const uint8_t* clamped;
     const GradRec* acc;
     int has_invdepth;
@@ -283,7 +284,11 @@ __global__ void __launch_bounds__(256, PRE_BWD_WAVES) preprocess_bwd_kernel(cons
     const int nrows = min(64, a.P - wave_g0);        // <= 0 for waves past the end
     if (nrows <= 0) return;
     const bool live = idx < a.P;
-    const bool rendered = live && a.radii[live ? idx : 0] > 0;
+    // A Gaussian takes part in the backward blend only through pixels that reached it in the
+    // forward (backward.cu:592-611 walks the pairs the forward blended).  One that no pixel
+    // reached, hidden behind saturated tiles, say, has an all-zero GradRec and with it zero
+    // gradients: it is treated like one that was culled, and its GradRec is not read.
+    const bool rendered = live && a.radii[live ? idx : 0] > 0 && a.gstat[live ? idx : 0].y > 0.0f;
     float* lds = reinterpret_cast<float*>(s_sh + w * WAVE_LDS);
     const uint64_t rows = __ballot(rendered);
     if (MODE == SH_CAT16) {
@@ -328,6 +333,7 @@ struct BatchView {
     float tanx, tany;
     int W, H, aa, has_invdepth;
     const int* radii;
+    const float2* gstat;
     const uint8_t* clamped;
     const GradRec* acc;
     float* dL_dmeans2D;  // [P,3] of this view, or null
@@ -356,10 +362,10 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
     float* lds = reinterpret_cast<float*>(s_sh + w * WAVE_LDS);
     float* row = lds + lane * REST_ROW_F;
 
-    uint32_t seen = 0;  // bit v: rendered in view v
+    uint32_t seen = 0;  // bit v: rendered in view v and reached by a pixel there (else its GradRec is zero)
     for (int v = 0; v < b.nviews; ++v) {
         if (!live) break;
-        if (b.v[v].radii[i] > 0) {
+        if (b.v[v].radii[i] > 0 && b.v[v].gstat[i].y > 0.0f) {
             seen |= 1u << v;
         } else if (b.v[v].dL_dmeans2D) {  // the screen-space gradient of a view is per view: zero here
             float* m2 = b.v[v].dL_dmeans2D + 3 * i;
@@ -554,7 +560,9 @@ hipError_t launch_preprocess_bwd_batch(const GsrScene& s, int nviews, const GsrB
             bv.tanx = gv.tanfovx; bv.tany = gv.tanfovy; bv.W = gv.W; bv.H = gv.H; bv.aa = gv.antialiasing;
             bv.has_invdepth = gv.has_invdepth;
             bv.radii = gv.radii;
-            bv.clamped = geom_buf(gv.geom_buffer, (size_t)s.P).clamped;
+            const GeomBuf gb = geom_buf(gv.geom_buffer, (size_t)s.P);
+            bv.clamped = gb.clamped;
+            bv.gstat = gb.gstat;
             bv.acc = (const GradRec*)gv.work;
             bv.dL_dmeans2D = gv.dL_dmeans2D;
         }
@@ -573,7 +581,7 @@ hipError_t launch_preprocess_bwd(const GsrScene& s, const int* radii, const Geom
     a.opacities = s.opacities; a.scales = s.scales; a.rotations = s.rotations;
     a.cov3D = s.cov3D_precomp;  // null: recomputed from scales and rotations
     a.cam.view = s.viewmatrix; a.cam.proj = s.projmatrix; a.cam.campos = s.campos;
-    a.radii = radii; a.clamped = g.clamped; a.acc = acc;
+    a.radii = radii; a.gstat = g.gstat; a.clamped = g.clamped; a.acc = acc;
     a.has_invdepth = io.dL_dout_invdepth != nullptr;
     a.dL_dmeans2D = io.dL_dmeans2D; a.dL_dcolors = io.dL_dcolors; a.dL_dopacity = io.dL_dopacity;
     a.dL_dmeans3D = io.dL_dmeans3D; a.dL_dcov3D = io.dL_dcov3D; a.dL_dsh = io.dL_dsh; a.dL_dsh_rest = io.dL_dsh_rest;

@@ -113,3 +113,39 @@ def test_everything_culled(oracle):
                      {}, out)
     for k, v in got.items():
         assert np.all(v == 0), k
+
+
+def test_hidden_gaussians_get_exactly_zero_gradients(oracle):
+    """A wall of opaque splats saturates every pixel before the Gaussians behind it are reached:
+    those are rendered (radius > 0, instances in the tile lists) but no pixel ever gets to them,
+    so the per-Gaussian backward treats them like culled ones.  Their gradients must be exactly
+    zero, as the checker's are, and everybody else's must still agree."""
+    sc = synth.tiny_scene(P=400, width=96, height=64, seed=61)
+    cam = sc["camera"]
+    view = np.asarray(cam["viewmatrix"], np.float32)   # row-vector convention: p_view = p @ view[:3,:3] + view[3,:3]
+    campos = np.asarray(cam["campos"], np.float32)
+    z_axis = view[:3, 2]
+    centre = sc["means3D"].mean(axis=0)
+    depth = float((centre - campos) @ z_axis)
+    # the first 40 Gaussians become a wall half way between the camera and the scene
+    rng = np.random.default_rng(5)
+    x_axis, y_axis = view[:3, 0], view[:3, 1]
+    uv = rng.uniform(-1.0, 1.0, (40, 2)).astype(np.float32) * 0.35 * depth
+    sc["means3D"][:40] = campos[None] + 0.5 * depth * z_axis[None] + uv[:, :1] * x_axis[None] + uv[:, 1:] * y_axis[None]
+    sc["scales"][:40] = 0.5 * depth
+    sc["opacities"].reshape(-1)[:40] = 0.99
+    rs, ten = scene_to_torch(sc, antialiasing=True)
+    f, out = _compare(oracle, sc, rs, ten, True, (0.0, 0.0, 0.0))
+    count = out["gauss_count"].cpu().numpy()
+    radii = out["radii"].cpu().numpy()
+    hidden = (radii > 0) & (count == 0)
+    assert hidden.sum() > 20, "the scene no longer hides anything: the test is vacuous"
+    H, W = rs.image_height, rs.image_width
+    rng = np.random.default_rng(7)
+    t = lambda a: torch.tensor(a, device="cuda:0")
+    got = _grads_gpu(rs, ten, t(rng.standard_normal((3, H, W)).astype(np.float32)),
+                     t(rng.standard_normal((1, H, W)).astype(np.float32)),
+                     t(rng.standard_normal((4, H, W)).astype(np.float32)), {}, out)
+    for k, v in got.items():
+        if v.shape[0] == hidden.shape[0]:
+            assert np.all(v[hidden] == 0), k
