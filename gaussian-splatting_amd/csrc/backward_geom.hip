@@ -521,19 +521,38 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
     }
 }
 
+// Zeroes the GradRecs the backward blend can add to: those of the Gaussians some pixel reached
+// in the forward.  The others are never read (see `rendered` / `seen` above), so a view costs
+// 8 bytes read per Gaussian and 64 written per reached one instead of a 64-byte fill of all.
+// Four lanes per record, 16 bytes each.
+__global__ void __launch_bounds__(256) clear_reached_kernel(int P, const float2* gstat, GradRec* acc) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = t >> 2;
+    if (i >= P) return;
+    if (gstat[i].y > 0.0f) reinterpret_cast<float4*>(acc + i)[t & 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+hipError_t launch_clear_reached(int P, const GeomBuf& g, GradRec* acc, hipStream_t st) {
+    const int64_t threads = (int64_t)P * 4;
+    hipLaunchKernelGGL(clear_reached_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, P, g.gstat, acc);
+    return hipGetLastError();
+}
+
 // dL/dmeans2D of one view straight from its GradRec (the only per-Gaussian
 // gradient a caller needs per view: the densification statistics read it).
-__global__ void __launch_bounds__(256) means2d_grad_kernel(int P, const GradRec* acc, float* dL_dmeans2D) {
+__global__ void __launch_bounds__(256) means2d_grad_kernel(int P, const float2* gstat, const GradRec* acc,
+                                                           float* dL_dmeans2D) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    const float2 g = *reinterpret_cast<const float2*>(acc + i);
+    float2 g = make_float2(0.f, 0.f);
+    if (gstat[i].y > 0.0f) g = *reinterpret_cast<const float2*>(acc + i);  // records nobody reached hold no data
     dL_dmeans2D[3 * (size_t)i] = g.x;
     dL_dmeans2D[3 * (size_t)i + 1] = g.y;
     dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
 }
 
-hipError_t launch_means2d_grad(int P, const GradRec* acc, float* dL_dmeans2D, hipStream_t st) {
-    hipLaunchKernelGGL(means2d_grad_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, acc, dL_dmeans2D);
+hipError_t launch_means2d_grad(int P, const GeomBuf& g, const GradRec* acc, float* dL_dmeans2D, hipStream_t st) {
+    hipLaunchKernelGGL(means2d_grad_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, g.gstat, acc, dL_dmeans2D);
     return hipGetLastError();
 }
 

@@ -153,7 +153,7 @@ static int backward_blend(const GsrScene* s, const int* radii, const void* geom_
     const ImageView im = image_view((void*)image_buffer, (size_t)s->W, (size_t)s->H);
     GradRec* acc = (GradRec*)io->work;
     mark(s, GSR_EV_BWD_BEGIN, st);
-    GSR_TRY(hipMemsetAsync(acc, 0, (size_t)s->P * sizeof(GradRec), st));
+    GSR_TRY(launch_clear_reached(s->P, g, acc, st));
     mark(s, GSR_EV_BWD_CLEAR, st);
     if (R > 0) {
         const BinView b = bin_view((void*)binning_buffer, (size_t)R);
@@ -198,7 +198,7 @@ int gsr_backward_blend(const GsrScene* s, const int* radii, const void* geom_buf
     const bool debug = s->debug != 0;
     rc = backward_blend(s, radii, geom_buffer, binning_buffer, image_buffer, R, io, st);
     if (rc != GSR_OK) return rc;
-    if (io->dL_dmeans2D) GSR_TRY(launch_means2d_grad(s->P, (const GradRec*)io->work, io->dL_dmeans2D, st));
+    if (io->dL_dmeans2D) GSR_TRY(launch_means2d_grad(s->P, geom_buf(geom_buffer, (size_t)s->P), (const GradRec*)io->work, io->dL_dmeans2D, st));
     mark(s, GSR_EV_BWD_PREPROCESS, st);
     return GSR_OK;
 }

@@ -97,7 +97,9 @@ hipError_t launch_render_bwd(const GsrScene& s, const GeomBuf& g, const ImageVie
 hipError_t launch_preprocess_bwd(const GsrScene& s, const int* radii, const GeomBuf& g, const GsrBackwardIO& io,
                                  const GradRec* acc, hipStream_t st);
 
-hipError_t launch_means2d_grad(int P, const GradRec* acc, float* dL_dmeans2D, hipStream_t st);
+hipError_t launch_means2d_grad(int P, const GeomBuf& g, const GradRec* acc, float* dL_dmeans2D, hipStream_t st);
+// Zeroes the records of the Gaussians that the forward's hit count marks as reached; the rest stay undefined.
+hipError_t launch_clear_reached(int P, const GeomBuf& g, GradRec* acc, hipStream_t st);
 hipError_t launch_preprocess_bwd_batch(const GsrScene& s, int nviews, const GsrBackwardView* views,
                                        const GsrBackwardIO& io, hipStream_t st);
 
