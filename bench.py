@@ -147,21 +147,25 @@ class KernelTimer:
         return out
 
 
-def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1):
+def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1, walked=None):
     """Bytes one launch must move at least: per-unit figures times the units one
     launch processes.  Preprocess and blend figures of the one-view kernels are
     those of the reference data layout; the binning stages and the two batch
     kernels (one launch for the V views of a step) are counted in this
     implementation's own layout, which is less than V times the one-view
-    figure: that saving is what they are for."""
+    figure: that saving is what they are for.  The units of the two blend
+    kernels are the list entries a launch walks (`walked`: per tile up to the
+    last instance one of its pixels blended), not all R sorted instances: at
+    this depth complexity a tile is saturated after a few per cent of its list."""
+    walked = R if walked is None else walked
     return {
         "preprocess": 315.0 * visible + 20.0 * (P - visible),
         "depth_order": P * (16.0 + 8.0 + 4.0 + 4 * 16.0),       # bin read, pair write, histogram read, 4 passes
         "emit_keys": P * (4.0 + 16.0 + 16.0 + 16.0) + 8.0 * R,  # gather + sbin write + sbin read, pair write
         "sort": R * (4.0 + passes * 16.0),
         "tile_ranges": 4.0 * R,
-        "render_fwd": 28.0 * R + 48.0 * HW,
-        "render_bwd": 60.0 * R + 40.0 * HW + 56.0 * R,
+        "render_fwd": 28.0 * walked + 48.0 * HW,
+        "render_bwd": 60.0 * walked + 40.0 * HW + 56.0 * walked,
         "preprocess_bwd": 575.0 * visible,
         # parameters (60 B) and SH row (192 B) read once; per view the 64-byte gradient record, radius and clamp
         # flags in, the screen-space gradient (12 B) out; the 63 parameter gradients written once
@@ -404,12 +408,24 @@ def main():
             pairs_l.append(int(o[4].sum(dtype=torch.int64).item()))   # (pixel, Gaussian) pairs the forward blend tested
         from diff_gaussian_rasterization import _C as RC
         e = torch.Tensor([])
+        import ctypes
+        from _gsplat_lib import GsrLayout, lib as gs_lib
+        walked_l = []
         for rs, _ in views:
-            R_l.append(int(RC.rasterize_gaussians(
+            o = RC.rasterize_gaussians(
                 rs.bg, params["xyz"], e, params["opacity"], params["scaling"], params["rotation"], 1.0, e,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, params["features_dc"], rs.sh_degree,
-                rs.campos, False, True, False, params["reps"], sh_rest=params["features_rest"], raw_params=True)[0]))
+                rs.campos, False, True, False, params["reps"], sh_rest=params["features_rest"], raw_params=True)
+            R_l.append(int(o[0]))
+            # list entries a tile walks: up to the last instance any of its pixels blended (what the backward blend
+            # stages; the forward stops within one staging round of it).  The rest of each list is sorted but never read.
+            lay = GsrLayout()
+            assert gs_lib().gsr_layout(P, W, H, R_l[-1], ctypes.byref(lay)) == 0
+            n = o[5][lay.n_contrib:lay.n_contrib + W * H * 4].view(torch.int32).reshape(H, W)
+            n = torch.nn.functional.pad(n, (0, gx * 16 - W, 0, gy * 16 - H))
+            walked_l.append(int(n.reshape(gy, 16, gx, 16).amax(dim=(1, 3)).sum(dtype=torch.int64).item()))
     visible, R, pairs = float(np.mean(vis_l)), float(np.mean(R_l)), float(np.mean(pairs_l))
+    walked = float(np.mean(walked_l))
 
     extras = {}
     if rank == 0 and world == 1 and not args.fwd_only and not args.no_extras:
@@ -511,7 +527,7 @@ def main():
         launches = lambda k: 1 if k in KernelTimer.PER_STEP else V          # per step
 
         def alg(k):
-            return algorithmic_bytes(k, P, visible, R, H * W, passes, V)
+            return algorithmic_bytes(k, P, visible, R, H * W, passes, V, walked)
 
         for k, ms in kernels.items():
             ab = alg(k)
@@ -546,6 +562,7 @@ def main():
                                 "PyTorch L1 / clamp around fused_ssim + reps L1 (as train.py)"),
                        "gaussians": P, "views_per_gpu_per_step": V, "visible_mean": visible, "num_rendered_mean": R,
                        "pairs_tested_mean": pairs, "tile_list_mean": R / (gx * gy),
+                       "instances_walked_mean": walked,
                        "image": [W, H], "parallelism": f"view-sharded x{world}, full replicas" if world > 1 else "single GPU",
                        "collective_backend": (backend if world > 1 else None)},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

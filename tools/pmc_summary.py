@@ -21,7 +21,7 @@ KERNEL_KEYS = {  # kernel symbol substring -> bench.py kernel name
     "sort_scan_hist_kernel": "sort:scan", "tile_ranges_kernel": "tile_ranges", "render_fwd_kernel": "render_fwd",
     "render_bwd_kernel": "render_bwd", "preprocess_bwd_kernel": "preprocess_bwd",
     "preprocess_bwd_batch_kernel": "preprocess_bwd_batch", "preprocess_fwd_batch_kernel": "preprocess_batch", "order_gather_kernel": "depth_order:gather", "ssim_fwd": "ssim_fwd",
-    "ssim_bwd": "ssim_bwd", "scan_blocks_kernel": "scan", "finish_gstat_kernel": "finish_stats"}
+    "ssim_bwd": "ssim_bwd", "scan_blocks_kernel": "scan", "finish_gstat_kernel": "finish_stats", "clear_reached_kernel": "bwd_clear"}
 
 
 def short(name, grid=0):
