@@ -104,6 +104,9 @@ def train_loss(out, gt, lambda_dssim=0.2, lambda_rep=0.01, fused=False):
         l1 = torch.abs(image - gt).mean()
         ssim_v = fused_ssim(image.unsqueeze(0), gt.unsqueeze(0))
         loss = (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim_v)
+    if fused:
+        from fused_ssim import l1_loss
+        return loss + lambda_rep * l1_loss(out[5], 10.0)
     return loss + lambda_rep * torch.abs(out[5] - 10.0).mean()
 
 
@@ -558,7 +561,7 @@ def main():
                                     "gradient all-reduce when n_gpus > 1; no optimizer"),
                        "api": "forward_params (raw parameters)" if use_params else "reference signature",
                        "streams": max(1, len(side_streams)),
-                       "loss": ("fused_ssim.l1_ssim_loss + reps L1" if fused_loss else
+                       "loss": ("fused_ssim.l1_ssim_loss + fused_ssim.l1_loss on the reps" if fused_loss else
                                 "PyTorch L1 / clamp around fused_ssim + reps L1 (as train.py)"),
                        "gaussians": P, "views_per_gpu_per_step": V, "visible_mean": visible, "num_rendered_mean": R,
                        "pairs_tested_mean": pairs, "tile_list_mean": R / (gx * gy),

@@ -116,6 +116,12 @@ def lib():
     L.gss_l1_ssim_loss_forward.argtypes = [C.c_int] * 3 + [C.c_float] * 3 + [_vp] * 8
     L.gss_l1_ssim_loss_backward.restype = C.c_int
     L.gss_l1_ssim_loss_backward.argtypes = [C.c_int] * 3 + [C.c_float] + [_vp] * 8
+    L.gss_l1_partial_floats.restype = C.c_size_t
+    L.gss_l1_partial_floats.argtypes = [C.c_int64]
+    L.gss_l1_loss_forward.restype = C.c_int
+    L.gss_l1_loss_forward.argtypes = [C.c_int64, _vp, _vp, C.c_float, _vp, _vp, _vp]
+    L.gss_l1_loss_backward.restype = C.c_int
+    L.gss_l1_loss_backward.argtypes = [C.c_int64, _vp, _vp, _vp, C.c_float, _vp, _vp]
     L.gso_adam_update.restype = C.c_int
     L.gso_adam_update.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int] + [C.c_double] * 6 + [_vp]
     L.gso_densify_stats.restype = C.c_int
@@ -137,6 +143,7 @@ EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backw
             "gsr_backward_geometry_batch", "gsr_preprocess_batch", "gsr_mark_visible", "gsr_sort_temp_bytes",
             "gsr_sort_pairs_u64_u32", "gsr_layout", "gsr_sorted_keys_u64", "gsk_dist2_temp_bytes", "gsk_dist2", "gss_ssim_forward",
             "gss_ssim_backward", "gss_loss_partial_floats", "gss_l1_ssim_loss_forward", "gss_l1_ssim_loss_backward",
+            "gss_l1_partial_floats", "gss_l1_loss_forward", "gss_l1_loss_backward",
             "gso_adam_update", "gso_densify_stats", "gso_compact_temp_bytes", "gso_compact_map",
             "gso_gather_rows", "gsr_status_string")
 

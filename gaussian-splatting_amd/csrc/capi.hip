@@ -384,6 +384,23 @@ int gss_l1_ssim_loss_backward(int planes, int H, int W, float lambda_dssim, cons
                                       dm_dsigma12, (hipStream_t)stream));
 }
 
+size_t gss_l1_partial_floats(int64_t n) { return n > 0 ? l1_partial_floats(n) : 0; }
+
+int gss_l1_loss_forward(int64_t n, const float* a, const float* b, float b_scalar, float* loss, float* partial,
+                        void* stream) {
+    if (n <= 0) return GSR_ERR_ARG;
+    if (!a || !loss || !partial) return GSR_ERR_ARG;
+    return hip_status(launch_l1_fwd(n, a, b, b_scalar, loss, partial, (hipStream_t)stream));
+}
+
+int gss_l1_loss_backward(int64_t n, const float* grad_loss, const float* a, const float* b, float b_scalar,
+                         float* dL_da, void* stream) {
+    if (n <= 0) return GSR_ERR_ARG;
+    if (!grad_loss || !a || !dL_da) return GSR_ERR_ARG;
+    if ((n + 255) / 256 >= (1ll << 31)) return GSR_ERR_OVERFLOW;
+    return hip_status(launch_l1_bwd(n, grad_loss, a, b, b_scalar, dL_da, (hipStream_t)stream));
+}
+
 int gso_adam_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible,
                     int64_t N, int M, double lr, double beta1, double beta2, double eps, double bias_correction1,
                     double bias_correction2_sqrt, void* stream) {

@@ -126,6 +126,11 @@ hipError_t launch_ssim_bwd(int B, int CH, int H, int W, const float* img1, const
                            hipStream_t st);
 
 size_t loss_partial_floats(int planes, int H, int W);
+size_t l1_partial_floats(int64_t n);
+hipError_t launch_l1_fwd(int64_t n, const float* a, const float* b, float b_scalar, float* loss, float* partial,
+                         hipStream_t st);
+hipError_t launch_l1_bwd(int64_t n, const float* grad_loss, const float* a, const float* b, float b_scalar,
+                         float* dL_da, hipStream_t st);
 hipError_t launch_loss_fwd(int planes, int H, int W, float C1, float C2, float lambda, const float* img,
                            const float* gt, float* loss, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
                            float* partial, hipStream_t st);

@@ -299,4 +299,70 @@ hipError_t launch_loss_bwd(int planes, int H, int W, float lambda, const float* 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ plain L1 loss
+// mean|a - b| (utils/loss_utils.py:23-24) with b a tensor or one number, in two kernels, and its
+// backward in one: what train.py:249-251 adds for the rendered feature channels costs seven
+// elementwise PyTorch kernels otherwise.  A fixed number of workgroups, each summing a strided
+// share in a fixed order; the second kernel sums their partial sums in double.
+constexpr int L1_MAX_BLOCKS = 1024;
+
+size_t l1_partial_floats(int64_t n) {
+    const int64_t nb = (n + 1023) / 1024;
+    return (size_t)(nb < 1 ? 1 : (nb > L1_MAX_BLOCKS ? L1_MAX_BLOCKS : nb));
+}
+
+__global__ void __launch_bounds__(256) l1_partial_kernel(int64_t n, const float* __restrict__ a,
+                                                         const float* __restrict__ b, float b_scalar,
+                                                         float* __restrict__ partial) {
+    __shared__ float s_w[4];
+    float acc = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        acc += fabsf(a[i] - (b ? b[i] : b_scalar));
+    const float w = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+__global__ void __launch_bounds__(256) l1_finish_kernel(const float* __restrict__ partial, int nb, double inv_count,
+                                                        float* __restrict__ loss) {
+    __shared__ double s_r[256];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) a += (double)partial[i];
+    s_r[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) s_r[threadIdx.x] += s_r[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(s_r[0] * inv_count);
+}
+
+// dL/da = grad / n * sign(a - b); sign(0) = 0 as torch.sign.  grad is a device scalar.
+__global__ void __launch_bounds__(256) l1_bwd_kernel(int64_t n, const float* __restrict__ grad_loss,
+                                                     const float* __restrict__ a, const float* __restrict__ b,
+                                                     float b_scalar, float inv_count, float* __restrict__ dL_da) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float g = grad_loss[0] * inv_count;
+    const float d = a[i] - (b ? b[i] : b_scalar);
+    dL_da[i] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+}
+
+hipError_t launch_l1_fwd(int64_t n, const float* a, const float* b, float b_scalar, float* loss, float* partial,
+                         hipStream_t st) {
+    const int nb = (int)l1_partial_floats(n);
+    hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, st, n, a, b, b_scalar, partial);
+    hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(256), 0, st, partial, nb, 1.0 / (double)n, loss);
+    return hipGetLastError();
+}
+
+hipError_t launch_l1_bwd(int64_t n, const float* grad_loss, const float* a, const float* b, float b_scalar,
+                         float* dL_da, hipStream_t st) {
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, grad_loss, a, b,
+                       b_scalar, (float)(1.0 / (double)n), dL_da);
+    return hipGetLastError();
+}
+
 }  // namespace gs

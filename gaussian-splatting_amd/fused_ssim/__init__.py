@@ -122,3 +122,52 @@ def l1_ssim_loss(image, gt, lambda_dssim=0.2, return_parts=False):
     `return_parts` also returns a detached tensor (loss, L1 mean, ssim mean) for logging."""
     loss, parts = _L1SSIMLoss.apply(image, gt, lambda_dssim)
     return (loss, parts) if return_parts else loss
+
+
+class _L1Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, b_scalar):
+        if not a.is_cuda:
+            raise RuntimeError("the first argument must be a GPU tensor (there is no CPU path)")
+        dev = a.device
+        x = a.contiguous().float()
+        y = None
+        if b is not None:
+            if b.shape != a.shape:
+                raise RuntimeError("l1_loss: both tensors must have the same shape")
+            y = b.to(dev).contiguous().float()
+        n = x.numel()
+        if n == 0:
+            raise RuntimeError("l1_loss of an empty tensor")
+        L = lib()
+        loss = torch.empty((1,), dtype=torch.float32, device=dev)
+        partial = torch.empty((L.gss_l1_partial_floats(n),), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.gss_l1_loss_forward(n, ptr(x), ptr(y) if y is not None else None, float(b_scalar), ptr(loss),
+                                        ptr(partial), stream_of(dev)), "l1_loss")
+        ctx.save_for_backward(x, y)
+        ctx.b_scalar = float(b_scalar)
+        ctx.set_materialize_grads(False)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        x, y = ctx.saved_tensors
+        if grad_loss is None:
+            return None, None, None
+        dev = x.device
+        g = grad_loss.contiguous().float()
+        out = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            check(lib().gss_l1_loss_backward(x.numel(), ptr(g), ptr(x), ptr(y) if y is not None else None, ctx.b_scalar,
+                                             ptr(out), stream_of(dev)), "l1_loss backward")
+        return out, None, None
+
+
+def l1_loss(network_output, gt):
+    """utils/loss_utils.py:23-24, `torch.abs(network_output - gt).mean()`, forward in two kernels
+    and backward in one (train.py:249 applies it to the rendered feature channels).  `gt` is a
+    tensor of the same shape or a number; the gradient goes to `network_output` only."""
+    if torch.is_tensor(gt):
+        return _L1Loss.apply(network_output, gt, 0.0)
+    return _L1Loss.apply(network_output, None, float(gt))

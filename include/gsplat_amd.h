@@ -285,6 +285,16 @@ int gss_l1_ssim_loss_backward(int planes, int H, int W, float lambda_dssim, cons
                               const float* gt, float* dL_dimg, const float* dm_dmu1, const float* dm_dsigma1_sq,
                               const float* dm_dsigma12, void* stream);
 
+/* mean|a - b| over n floats (utils/loss_utils.py:23-24, used at train.py:222 and :249 for the
+ * rendered feature channels), b a device array or, when b is NULL, the number b_scalar: forward
+ * in two kernels (loss: device [1]; `partial`: scratch of gss_l1_partial_floats(n) floats),
+ * backward in one: dL_da[i] = *grad_loss / n * sign(a[i] - b[i]), *grad_loss a device scalar. */
+size_t gss_l1_partial_floats(int64_t n);
+int gss_l1_loss_forward(int64_t n, const float* a, const float* b, float b_scalar, float* loss, float* partial,
+                        void* stream);
+int gss_l1_loss_backward(int64_t n, const float* grad_loss, const float* a, const float* b, float b_scalar,
+                         float* dL_da, void* stream);
+
 /* Fused Adam step over one parameter tensor [N, M] (row = Gaussian), in place.
  * Replaces, for the model's parameter groups, torch.optim.Adam as configured at
  * scene/gaussian_model.py:112-113 (same operation order as its single-tensor path) and provides

@@ -132,3 +132,26 @@ def test_l1_ssim_loss_equals_the_composed_formulation(shape, lam):
     scale = float(a.grad.abs().max())
     assert float((b.grad - a.grad).abs().max()) <= 2e-6 * scale
     assert torch.equal(b.grad == 0, a.grad == 0)
+
+
+@pytest.mark.parametrize("shape,target", [((4, 37, 53), "tensor"), ((4, 1080, 1920), 10.0), ((1, 5), "tensor"),
+                                          ((3, 300, 500), -0.25)])
+def test_l1_loss_equals_torch(shape, target):
+    """fused_ssim.l1_loss against torch.abs(a - b).mean() (utils/loss_utils.py:23-24) and its autograd
+    gradient, with a tensor and with a number as the target; exact zeros in a - b get sign 0."""
+    import fused_ssim
+    g = torch.Generator(device="cuda:0").manual_seed(11)
+    a = torch.randn(shape, device="cuda:0", generator=g) * 3
+    b = torch.randn(shape, device="cuda:0", generator=g) if target == "tensor" else target
+    if target == "tensor":
+        a.view(-1)[::7] = b.view(-1)[::7]              # ties: the gradient there is zero
+    a1 = a.clone().requires_grad_(True)
+    a2 = a.clone().requires_grad_(True)
+    got = fused_ssim.l1_loss(a1, b)
+    ref = torch.abs(a2 - b).mean()
+    assert abs(got.item() - ref.item()) <= 1e-6 * max(1.0, abs(ref.item()))
+    (2.5 * got).backward()
+    (2.5 * ref).backward()
+    assert torch.allclose(a1.grad, a2.grad, rtol=1e-6, atol=0)
+    if target == "tensor":
+        assert (a1.grad.view(-1)[::7] == 0).all()

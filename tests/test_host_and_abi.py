@@ -87,6 +87,10 @@ def test_argument_validation_without_gpu():
     assert L.gss_l1_ssim_loss_forward(3, 8, 8, 1e-4, 9e-4, 0.2, None, None, None, None, None, None, None, None) == -1
     assert L.gss_l1_ssim_loss_backward(3, 8, 8, 0.2, None, None, None, None, None, None, None, None) == -1
     assert L.gss_l1_ssim_loss_forward(0, 8, 8, 1e-4, 9e-4, 0.2, None, None, None, None, None, None, None, None) == -1
+    assert L.gss_l1_partial_floats(0) == 0 and L.gss_l1_partial_floats(5) == 1 and L.gss_l1_partial_floats(1 << 30) == 1024
+    assert L.gss_l1_loss_forward(10, None, None, 0.0, None, None, None) == -1
+    assert L.gss_l1_loss_forward(0, None, None, 0.0, None, None, None) == -1
+    assert L.gss_l1_loss_backward(10, None, None, None, 0.0, None, None) == -1
     kept = C.c_int64(5)
     assert L.gso_compact_temp_bytes(1000) >= 4 * 5
     assert L.gso_compact_map(0, None, None, None, 0, C.byref(kept), None) == 0 and kept.value == 0
@@ -133,6 +137,8 @@ def test_operator_layer_mirrors_reference_checks():
         fused_ssim.fused_ssim(torch.zeros(1, 3, 16, 16), torch.zeros(1, 3, 16, 16), padding="full")
     with pytest.raises(RuntimeError, match="no CPU path"):
         fused_ssim.l1_ssim_loss(torch.zeros(3, 16, 16), torch.zeros(3, 16, 16))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        fused_ssim.l1_loss(torch.zeros(3, 16, 16), 1.0)
     from gsplat_optim import RowCompactor
     with pytest.raises(RuntimeError, match="no CPU path"):
         RowCompactor(torch.ones(10, dtype=torch.bool))
