@@ -113,7 +113,7 @@ def train_loss(out, gt, lambda_dssim=0.2, lambda_rep=0.01, fused=False):
 class KernelTimer:
     """HIP events recorded by the library around its kernels, one set per rendered view."""
 
-    PAIRS = {"preprocess": (0, 1), "scan": (1, 2), "host_sync_gap": (2, 3), "depth_order": (3, 4), "emit_keys": (4, 5), "sort": (5, 6),
+    PAIRS = {"preprocess": (0, 1), "scan": (1, 2), "host_sync_gap": (2, 3), "tile_count": (3, 18), "depth_order": (18, 4), "emit_keys": (4, 5), "sort": (5, 6),
              "tile_ranges": (6, 7), "render_fwd": (7, 8), "finish_stats": (8, 9), "bwd_clear": (10, 11),
              "render_bwd": (11, 12), "preprocess_bwd": (12, 13), "preprocess_bwd_batch": (14, 15),
              "preprocess_batch": (16, 17)}
@@ -150,7 +150,7 @@ class KernelTimer:
         return out
 
 
-def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1, walked=None):
+def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1, walked=None, from_rects=True):
     """Bytes one launch must move at least: per-unit figures times the units one
     launch processes.  Preprocess and blend figures of the one-view kernels are
     those of the reference data layout; the binning stages and the two batch
@@ -165,8 +165,11 @@ def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1, walked=None):
         "preprocess": 315.0 * visible + 20.0 * (P - visible),
         "depth_order": P * (16.0 + 8.0 + 4.0 + 4 * 16.0),       # bin read, pair write, histogram read, 4 passes
         "emit_keys": P * (4.0 + 16.0 + 16.0 + 16.0) + 8.0 * R,  # gather + sbin write + sbin read, pair write
-        "sort": R * (4.0 + passes * 16.0),
-        "tile_ranges": 4.0 * R,
+        # the digit histograms and the tile ranges come from the tile rectangles (16 B per Gaussian) when the
+        # tile grid fits one workgroup's LDS; otherwise from a histogram sweep and a range scan over the keys
+        "tile_count": P * 16.0 if from_rects else None,
+        "sort": R * ((0.0 if from_rects else 4.0) + passes * 16.0),
+        "tile_ranges": None if from_rects else 4.0 * R,
         "render_fwd": 28.0 * walked + 48.0 * HW,
         "render_bwd": 60.0 * walked + 40.0 * HW + 56.0 * walked,
         "preprocess_bwd": 575.0 * visible,
@@ -181,7 +184,7 @@ def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1, walked=None):
 
 # What bounds each kernel (the blend kernels stop early per pixel and are limited by
 # VALU / LDS issue, not by the bytes they move; the others stream through HBM).
-BOUND = {"preprocess_bwd_batch": "hbm", "preprocess_batch": "hbm", "preprocess": "hbm", "depth_order": "hbm", "emit_keys": "hbm", "sort": "hbm", "tile_ranges": "hbm",
+BOUND = {"tile_count": "hbm", "preprocess_bwd_batch": "hbm", "preprocess_batch": "hbm", "preprocess": "hbm", "depth_order": "hbm", "emit_keys": "hbm", "sort": "hbm", "tile_ranges": "hbm",
          "render_fwd": "valu+lds", "render_bwd": "valu+lds+atomics", "preprocess_bwd": "hbm"}
 
 
@@ -401,6 +404,7 @@ def main():
         kernels["means2d_grad"] = kernels.pop("preprocess_bwd")   # in deferred mode that slot times the gradient copy
     gx, gy = (W + 15) // 16, (H + 15) // 16
     passes = ((gx * gy).bit_length() + 7) // 8   # the instance sort only orders the tile bits
+    from_rects = ((gx + 1) * (gy + 1) + passes * 256 + 17) * 4 <= 150 * 1024   # as tile_counts_fit in the library
 
     # workload counters of this rank's views (outside the timed region)
     vis_l, R_l, pairs_l = [], [], []
@@ -530,7 +534,7 @@ def main():
         launches = lambda k: 1 if k in KernelTimer.PER_STEP else V          # per step
 
         def alg(k):
-            return algorithmic_bytes(k, P, visible, R, H * W, passes, V, walked)
+            return algorithmic_bytes(k, P, visible, R, H * W, passes, V, walked, from_rects)
 
         for k, ms in kernels.items():
             ab = alg(k)
@@ -578,7 +582,7 @@ def main():
             # the reference's sort (R pairs of u64 key + u32 value) is done here by the depth ordering of the
             # Gaussians plus the sort of the instances on their tile id: payload rate over both
             "sort_GBps": (R * 12.0 / ((kernels["sort"] + kernels["depth_order"]) * 1e-3) / 1e9) if R else None,
-            "sort_hbm_GBps": (R * (4.0 + passes * 16.0) / (kernels["sort"] * 1e-3) / 1e9) if R else None,
+            "sort_hbm_GBps": (R * ((0.0 if from_rects else 4.0) + passes * 16.0) / (kernels["sort"] * 1e-3) / 1e9) if R else None,
         }
         if overlapping:
             res["kernels_in_timed_region_ms"] = kernels_overlapped

@@ -148,10 +148,10 @@ EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backw
             "gso_gather_rows", "gsr_status_string")
 
 
-NUM_PROFILE_EVENTS = 18
+NUM_PROFILE_EVENTS = 19
 EVENT_NAMES = ("stage1_begin", "preprocess", "scan", "stage2_begin", "depth_order", "emit", "sort", "ranges", "render",
                "finish", "bwd_begin", "bwd_clear", "bwd_render", "bwd_preprocess", "batch_begin", "batch",
-               "fwd_batch_begin", "fwd_batch")
+               "fwd_batch_begin", "fwd_batch", "tile_count")
 
 # Optional per-thread hook used by bench.py: a ctypes array of hipEvent_t handles
 # that the next rasterizer calls record around their kernels.

@@ -110,6 +110,17 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
         BinView b = bin_view(binning_buffer, (size_t)R);
         int res = 0;
         mark(s, GSR_EV_STAGE2_BEGIN, st);
+        const int nbits = tile_bits(s->W, s->H), passes = sort_passes_for(0, nbits);
+        // the tile ranges and the sort's histograms from the tile rectangles, when the tile grid fits one
+        // workgroup's LDS; otherwise from the keys (a histogram sweep before the sort, a range scan after it)
+        const bool from_rects = R > 0 && tile_counts_fit(s->W, s->H, passes);
+        if (from_rects) {
+            hipError_t e = hipSuccess;
+            uint32_t* ghist = sort_prepare(b.sort_temp, R, passes, st, &e);
+            GSR_TRY(e);
+            GSR_TRY(launch_tile_ranges_from_rects(g, s->P, s->W, s->H, im, ghist, passes, nbits, st));
+        }
+        mark(s, GSR_EV_TILE_COUNT, st);
         if (R > 0) {
             int ord = 0;
             // only the Gaussians with instances are ordered when stage 1 reported how many there are
@@ -119,10 +130,10 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
             GSR_TRY(launch_emit_keys(*s, g, g.dvals[ord], n, b.keys[0], b.vals[0], st));
             mark(s, GSR_EV_EMIT, st);
             // emission order is (depth, index): the stable sort only has to order the tile ids
-            GSR_TRY(launch_radix_sort_u32(b.keys, b.vals, R, 0, tile_bits(s->W, s->H), b.sort_temp, st, &res, false));
+            GSR_TRY(launch_radix_sort_u32(b.keys, b.vals, R, 0, nbits, b.sort_temp, st, &res, from_rects));
             mark(s, GSR_EV_SORT, st);
         }
-        GSR_TRY(launch_tile_ranges(b.keys[res], R, im.ranges, ntiles, st));
+        if (!from_rects) GSR_TRY(launch_tile_ranges(b.keys[res], R, im.ranges, ntiles, st));
         mark(s, GSR_EV_RANGES, st);
         point_list = b.vals[res];
     }

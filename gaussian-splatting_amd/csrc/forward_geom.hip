@@ -419,6 +419,146 @@ __global__ void __launch_bounds__(PRE_BLOCK) emit_keys_kernel(int P, int grid_x,
     }
 }
 
+// Tile ranges and the sort's digit histograms without reading the instances: how many instances
+// a tile gets is how many tile rectangles cover it, and that follows from the rectangles alone.
+// Every rectangle marks its four corners in a (grid_y + 1) x (grid_x + 1) array (+1 at two, -1 at
+// the other two); the two-dimensional prefix sum of the marks is the cover count per tile, the
+// running sum of the counts in tile order gives the ranges that identifyTileRanges
+// (rasterizer_impl.cu:115-137) finds by scanning the sorted keys, and the counts summed per
+// digit are the histograms the radix passes start from.  Per view this reads 16 bytes per
+// Gaussian instead of two sweeps over the instances (histogram and range scan).
+constexpr int TC_THREADS = 1024;
+constexpr int TC_BLOCKS = 256;
+constexpr int TF_THREADS = 1024;
+constexpr size_t TILE_LDS_LIMIT = 150 * 1024;
+
+size_t tile_finish_lds(int gx, int gy, int passes) {
+    return ((size_t)(gx + 1) * (gy + 1) + (size_t)passes * 256 + TF_THREADS / 64 + 1) * sizeof(int);
+}
+
+bool tile_counts_fit(int W, int H, int passes) {
+    const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
+    return tile_finish_lds(gx, gy, passes) <= TILE_LDS_LIMIT;
+}
+
+__global__ void __launch_bounds__(TC_THREADS) tile_count_kernel(int P, const uint4* __restrict__ bin, int gx, int gy,
+                                                               int* __restrict__ diff) {
+    extern __shared__ int s_diff[];
+    const int nd = (gx + 1) * (gy + 1), pitch = gx + 1;
+    for (int i = threadIdx.x; i < nd; i += TC_THREADS) s_diff[i] = 0;
+    __syncthreads();
+    // four independent loads in flight per lane: the loop is bound by their latency
+    const int stride = gridDim.x * TC_THREADS;
+    for (int i0 = blockIdx.x * TC_THREADS + threadIdx.x; i0 < P; i0 += 4 * stride) {
+        uint4 b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * stride;
+            b[u] = i < P ? bin[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (b[u].w == 0) continue;
+            const int x0 = (int)(b[u].x & 0xffffu), y0 = (int)(b[u].x >> 16);
+            const int x1 = x0 + (int)(b[u].y & 0xffffu), y1 = y0 + (int)(b[u].y >> 16);
+            atomicAdd(&s_diff[y0 * pitch + x0], 1);
+            atomicAdd(&s_diff[y0 * pitch + x1], -1);
+            atomicAdd(&s_diff[y1 * pitch + x0], -1);
+            atomicAdd(&s_diff[y1 * pitch + x1], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nd; i += TC_THREADS) {
+        const int v = s_diff[i];
+        if (v) atomicAdd(&diff[i], v);
+    }
+}
+
+// One workgroup: prefix sums of the corner marks along x and y, then the running sum over the
+// tiles in key order.  A tile without instances keeps the range (0, 0), as in the reference,
+// whose ranges are zero-filled and written only where the sorted keys change.
+__global__ void __launch_bounds__(TF_THREADS) tile_finish_kernel(int gx, int gy, const int* __restrict__ diff,
+                                                                 uint2* __restrict__ ranges, uint32_t* __restrict__ ghist,
+                                                                 int passes, int nbits) {
+    extern __shared__ int s_all[];
+    const int pitch = gx + 1, nd = pitch * (gy + 1), ntiles = gx * gy;
+    int* s_c = s_all;                                                  // [nd] marks, then cover counts
+    uint32_t* s_h = reinterpret_cast<uint32_t*>(s_all + nd);           // [passes][256]
+    uint32_t* s_w = s_h + passes * 256;                                // [waves + 1]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < nd; i += TF_THREADS) s_c[i] = diff[i];
+    for (int i = tid; i < passes * 256; i += TF_THREADS) s_h[i] = 0;
+    __syncthreads();
+    // running sums along x, then along y: one wave per line, 64 elements per step
+    constexpr int NWAVES = TF_THREADS / 64;
+    for (int r = w; r <= gy; r += NWAVES) {
+        uint32_t carry = 0;
+        for (int x0 = 0; x0 <= gx; x0 += 64) {
+            const int x = x0 + lane;
+            const uint32_t v = x <= gx ? (uint32_t)s_c[r * pitch + x] : 0u;
+            const uint32_t incl = wave_scan_incl_u32(v) + carry;
+            if (x <= gx) s_c[r * pitch + x] = (int)incl;
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+    }
+    __syncthreads();
+    for (int c = w; c <= gx; c += NWAVES) {
+        uint32_t carry = 0;
+        for (int y0 = 0; y0 <= gy; y0 += 64) {
+            const int y = y0 + lane;
+            const uint32_t v = y <= gy ? (uint32_t)s_c[y * pitch + c] : 0u;
+            const uint32_t incl = wave_scan_incl_u32(v) + carry;
+            if (y <= gy) s_c[y * pitch + c] = (int)incl;
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+    }
+    __syncthreads();
+    // thread t owns `chunk` consecutive tiles
+    const int chunk = (ntiles + TF_THREADS - 1) / TF_THREADS;
+    const int t0 = tid * chunk, t1 = min(ntiles, t0 + chunk);
+    uint32_t mine = 0;
+    for (int t = t0; t < t1; ++t) mine += (uint32_t)s_c[(t / gx) * pitch + (t % gx)];
+    const uint32_t incl = wave_scan_incl_u32(mine);
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    uint32_t start = incl - mine;
+    for (int k = 0; k < w; ++k) start += s_w[k];
+    for (int t = t0; t < t1; ++t) {
+        const uint32_t c = (uint32_t)s_c[(t / gx) * pitch + (t % gx)];
+        ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);
+        if (c) {
+            for (int p = 0; p < passes; ++p) {
+                int shift, bits;
+                digit_of_pass(nbits, passes, p, &shift, &bits);
+                atomicAdd(&s_h[p * 256 + (((uint32_t)t >> shift) & ((1u << bits) - 1))], c);
+            }
+        }
+        start += c;
+    }
+    __syncthreads();
+    for (int i = tid; i < passes * 256; i += TF_THREADS) ghist[i] = s_h[i];
+}
+
+hipError_t launch_tile_ranges_from_rects(const GeomBuf& g, int P, int W, int H, const ImageView& im, uint32_t* ghist,
+                                         int passes, int nbits, hipStream_t st) {
+    const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
+    const size_t nd = (size_t)(gx + 1) * (gy + 1);
+    hipError_t e = hipMemsetAsync(im.tile_diff, 0, nd * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    const size_t lds_c = nd * sizeof(int), lds_f = tile_finish_lds(gx, gy, passes);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_c);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_f);
+    if (e != hipSuccess) return e;
+    const int blocks = min(TC_BLOCKS, (P + TC_THREADS - 1) / TC_THREADS);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(blocks), dim3(TC_THREADS), lds_c, st, P, g.bin, gx, gy, im.tile_diff);
+    hipLaunchKernelGGL(tile_finish_kernel, dim3(1), dim3(TF_THREADS), lds_f, st, gx, gy, im.tile_diff, im.ranges, ghist,
+                       passes, nbits);
+    return hipGetLastError();
+}
+
 // rasterizer_impl.cu:115-137, on the sorted tile ids.
 __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* keys, int64_t R, uint2* ranges) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -328,6 +328,7 @@ struct ImageView {
     float* final_T;       // [H*W]
     uint32_t* n_contrib;  // [H*W]
     uint2* ranges;        // [tiles]
+    int* tile_diff;       // [(grid_y + 1) * (grid_x + 1)] corner marks of the tile rectangles (scratch of the forward)
     size_t bytes;
 };
 
@@ -341,6 +342,7 @@ inline ImageView image_view(void* base, size_t W, size_t H) {
     v.final_T = (float*)take(N * sizeof(float));
     v.n_contrib = (uint32_t*)take(N * sizeof(uint32_t));
     v.ranges = (uint2*)take(ntiles * sizeof(uint2));
+    v.tile_diff = (int*)take(((W + TILE_X - 1) / TILE_X + 1) * ((H + TILE_Y - 1) / TILE_Y + 1) * sizeof(int));
     v.bytes = off;
     return v;
 }
@@ -350,6 +352,14 @@ inline ImageView image_view(void* base, size_t W, size_t H) {
 #endif
 constexpr int SORT_TILE = GS_SORT_TILE;   // keys per onesweep workgroup
 constexpr int SORT_MAX_PASSES = 8;
+
+// The key bits are dealt evenly to the passes (13 bits: 7 + 6, not 8 + 5): the fewer buckets a
+// pass has, the longer the contiguous run a tile writes into each of them.
+__host__ __device__ inline void digit_of_pass(int nbits, int passes, int p, int* shift, int* bits) {
+    const int base = nbits / passes, extra = nbits % passes;
+    *bits = base + (p < extra ? 1 : 0);
+    *shift = p * base + (p < extra ? p : extra);
+}
 
 struct SortTemp {
     uint32_t* ghist;    // [SORT_MAX_PASSES][256] digit histograms, then exclusive bases

@@ -86,6 +86,13 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* view, u
 // Returns the index (0/1) of the buffer pair that holds the sorted result.
 hipError_t launch_radix_sort(uint64_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit, void* temp,
                              hipStream_t st, int* result_buffer);
+// Zeroes the sort's status area and returns where its digit histograms go (for a caller that fills them itself).
+uint32_t* sort_prepare(void* temp, int64_t n, int passes, hipStream_t st, hipError_t* e);
+// Tile ranges and the instance sort's digit histograms from the tile rectangles (image sizes whose
+// tile grid fits the LDS of one workgroup: tile_counts_fit).
+bool tile_counts_fit(int W, int H, int passes);
+hipError_t launch_tile_ranges_from_rects(const GeomBuf& g, int P, int W, int H, const ImageView& im, uint32_t* ghist,
+                                         int passes, int nbits, hipStream_t st);
 // The same with 32-bit keys.  hist_ready: the digit histograms in the temp area were filled by the caller.
 hipError_t launch_radix_sort_u32(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit,
                                  void* temp, hipStream_t st, int* result_buffer, bool hist_ready);

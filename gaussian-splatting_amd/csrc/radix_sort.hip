@@ -25,14 +25,6 @@ constexpr int LOOK_BATCH = GS_LOOK_BATCH;
 
 int sort_passes_for(int begin_bit, int end_bit) { return (end_bit - begin_bit + 7) / 8; }
 
-// The key bits are dealt evenly to the passes (13 bits: 7 + 6, not 8 + 5): the fewer buckets a
-// pass has, the longer the contiguous run a tile writes into each of them.
-__host__ __device__ inline void digit_of_pass(int nbits, int passes, int p, int* shift, int* bits) {
-    const int base = nbits / passes, extra = nbits % passes;
-    *bits = base + (p < extra ? 1 : 0);
-    *shift = p * base + (p < extra ? p : extra);
-}
-
 // Digit histograms of all passes in one read of the keys, 16 bytes per lane and load (a lane
 // that reads one key per trip spends its time waiting for that load).
 template <class K>

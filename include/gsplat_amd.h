@@ -108,7 +108,8 @@ typedef enum {
     GSR_EV_BATCH = 15,         /* per-Gaussian backward of a batch of views (gsr_backward_geometry_batch) */
     GSR_EV_FWD_BATCH_BEGIN = 16,
     GSR_EV_FWD_BATCH = 17,     /* preprocess of a batch of views (gsr_preprocess_batch) */
-    GSR_NUM_PROFILE_EVENTS = 18
+    GSR_EV_TILE_COUNT = 18,    /* tile ranges and sort histograms from the tile rectangles (after STAGE2_BEGIN, before the depth order) */
+    GSR_NUM_PROFILE_EVENTS = 19
 } GsrProfileEvent;
 
 /* Outputs of the forward pass.  None of them needs initialising by the caller. */

@@ -21,7 +21,7 @@ KERNEL_KEYS = {  # kernel symbol substring -> bench.py kernel name
     "sort_scan_hist_kernel": "sort:scan", "tile_ranges_kernel": "tile_ranges", "render_fwd_kernel": "render_fwd",
     "render_bwd_kernel": "render_bwd", "preprocess_bwd_kernel": "preprocess_bwd",
     "preprocess_bwd_batch_kernel": "preprocess_bwd_batch", "preprocess_fwd_batch_kernel": "preprocess_batch", "order_gather_kernel": "depth_order:gather", "ssim_fwd": "ssim_fwd",
-    "ssim_bwd": "ssim_bwd", "scan_blocks_kernel": "scan", "finish_gstat_kernel": "finish_stats", "clear_reached_kernel": "bwd_clear"}
+    "ssim_bwd": "ssim_bwd", "scan_blocks_kernel": "scan", "finish_gstat_kernel": "finish_stats", "clear_reached_kernel": "bwd_clear", "tile_count_kernel": "tile_count:count", "tile_finish_kernel": "tile_count:finish"}
 
 
 def short(name, grid=0):
@@ -38,7 +38,9 @@ def short(name, grid=0):
 
 # bench.py kernel name -> (detail name, launches per view) that make it up
 COMPOSED = {
+    # "sort:hist" only when the tile grid is too large for the rectangle-count path (then "tile_count" is absent)
     "sort": (("sort:hist", 1), ("sort:scan", 1), ("sort:onesweep", 2)),
+    "tile_count": (("tile_count:count", 1), ("tile_count:finish", 1)),
     "depth_order": (("depth_order:keys", 1), ("depth_order:hist", 1), ("depth_order:onesweep", 4)),
     "emit_keys": (("depth_order:gather", 1), ("emit_keys", 1)),
 }
@@ -81,7 +83,7 @@ def main():
         json.dump({k: traffic[k] for k in sorted(traffic)}, f, indent=1)
     simple = {k: v for k, v in traffic.items() if ":" not in k}
     for name, parts in COMPOSED.items():
-        if all(d in traffic for d, _ in parts if d != "sort:scan"):
+        if all(d in traffic for d, _ in parts if d not in ("sort:scan", "sort:hist")):
             simple[name] = sum(traffic.get(d, 0.0) * n for d, n in parts)
     out_d = {k: simple[k] for k in sorted(simple)}
     out_d["_workload"] = [6000000, 1920, 1080]   # bench.py defaults, which tools/collect_pmc.sh runs
