@@ -149,3 +149,13 @@ def test_hidden_gaussians_get_exactly_zero_gradients(oracle):
     for k, v in got.items():
         if v.shape[0] == hidden.shape[0]:
             assert np.all(v[hidden] == 0), k
+
+
+def test_tile_grid_too_large_for_the_rectangle_count_path(oracle):
+    """Tile ranges and the sort's histograms normally come from the tile rectangles, in the LDS of
+    one workgroup; a 640 x 64 tile grid does not fit there, so this image takes the other path
+    (histogram sweep over the keys, range scan over the sorted keys).  Same bars."""
+    sc = synth.tiny_scene(P=300, width=10240, height=1024, seed=71, scale=0.05)
+    rs, ten = scene_to_torch(sc, antialiasing=True)
+    f, out = _compare(oracle, sc, rs, ten, True, (0.0, 0.0, 0.0))
+    assert f.R > 100000
