@@ -114,7 +114,18 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
         // the tile ranges and the sort's histograms from the tile rectangles, when the tile grid fits one
         // workgroup's LDS; otherwise from the keys (a histogram sweep before the sort, a range scan after it)
         const bool from_rects = R > 0 && tile_counts_fit(s->W, s->H, passes);
-        if (from_rects) {
+        // only the Gaussians with instances are ordered when stage 1 reported how many there are
+        const int n = (o->num_visible > 0 && o->num_visible <= s->P) ? (int)o->num_visible : s->P;
+        // two-digit tile ids: the emission partitions by the high digit, one segmented pass does the low one
+        const bool fused = from_rects && fused_sort_fits(R, n, nbits);
+        if (fused) {
+            uint32_t *ghist, *seg_start, *seg_tile0;
+            int lowshift, lowbits;
+            digit_of_pass(nbits, 2, 0, &lowshift, &lowbits);
+            GSR_TRY(fused_sort_prepare(b.sort_temp, R, n, nbits, st, &ghist, &seg_start, &seg_tile0));
+            GSR_TRY(launch_tile_ranges_from_rects(g, s->P, s->W, s->H, im, ghist, passes, nbits, st, lowbits, seg_start,
+                                                  seg_tile0));
+        } else if (from_rects) {
             hipError_t e = hipSuccess;
             uint32_t* ghist = sort_prepare(b.sort_temp, R, passes, st, &e);
             GSR_TRY(e);
@@ -123,14 +134,20 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
         mark(s, GSR_EV_TILE_COUNT, st);
         if (R > 0) {
             int ord = 0;
-            // only the Gaussians with instances are ordered when stage 1 reported how many there are
-            const int n = (o->num_visible > 0 && o->num_visible <= s->P) ? (int)o->num_visible : s->P;
             GSR_TRY(launch_depth_order(g, s->P, n, st, &ord));
             mark(s, GSR_EV_DEPTH_ORDER, st);
-            GSR_TRY(launch_emit_keys(*s, g, g.dvals[ord], n, b.keys[0], b.vals[0], st));
-            mark(s, GSR_EV_EMIT, st);
-            // emission order is (depth, index): the stable sort only has to order the tile ids
-            GSR_TRY(launch_radix_sort_u32(b.keys, b.vals, R, 0, nbits, b.sort_temp, st, &res, from_rects));
+            if (fused) {
+                GSR_TRY(launch_order_gather(g, g.dvals[ord], n, st));
+                GSR_TRY(launch_emit_partition(g, n, (s->W + TILE_X - 1) / TILE_X, nbits, R, b.keys, b.vals, b.sort_temp, st));
+                mark(s, GSR_EV_EMIT, st);
+                GSR_TRY(launch_segmented_pass(n, ntiles, nbits, R, im.ranges, b.keys, b.vals, b.sort_temp, st));
+                res = 0;
+            } else {
+                GSR_TRY(launch_emit_keys(*s, g, g.dvals[ord], n, b.keys[0], b.vals[0], st));
+                mark(s, GSR_EV_EMIT, st);
+                // emission order is (depth, index): the stable sort only has to order the tile ids
+                GSR_TRY(launch_radix_sort_u32(b.keys, b.vals, R, 0, nbits, b.sort_temp, st, &res, from_rects));
+            }
             mark(s, GSR_EV_SORT, st);
         }
         if (!from_rects) GSR_TRY(launch_tile_ranges(b.keys[res], R, im.ranges, ntiles, st));

@@ -433,7 +433,7 @@ constexpr int TF_THREADS = 1024;
 constexpr size_t TILE_LDS_LIMIT = 150 * 1024;
 
 size_t tile_finish_lds(int gx, int gy, int passes) {
-    return ((size_t)(gx + 1) * (gy + 1) + (size_t)passes * 256 + TF_THREADS / 64 + 1) * sizeof(int);
+    return ((size_t)(gx + 1) * (gy + 1) + (size_t)passes * 256 + TF_THREADS / 64 + 1 + 2 * 260) * sizeof(int);
 }
 
 bool tile_counts_fit(int W, int H, int passes) {
@@ -477,14 +477,20 @@ __global__ void __launch_bounds__(TC_THREADS) tile_count_kernel(int P, const uin
 // One workgroup: prefix sums of the corner marks along x and y, then the running sum over the
 // tiles in key order.  A tile without instances keeps the range (0, 0), as in the reference,
 // whose ranges are zero-filled and written only where the sorted keys change.
+// With seg_start: also where the instances of each value of the high digit (tile id >> lowbits, a
+// "segment") start, and the first sort-pass tile of each segment when no tile straddles two.
 __global__ void __launch_bounds__(TF_THREADS) tile_finish_kernel(int gx, int gy, const int* __restrict__ diff,
                                                                  uint2* __restrict__ ranges, uint32_t* __restrict__ ghist,
-                                                                 int passes, int nbits) {
+                                                                 int passes, int nbits, int lowbits, int nseg,
+                                                                 uint32_t* __restrict__ seg_start,
+                                                                 uint32_t* __restrict__ seg_tile0) {
     extern __shared__ int s_all[];
     const int pitch = gx + 1, nd = pitch * (gy + 1), ntiles = gx * gy;
     int* s_c = s_all;                                                  // [nd] marks, then cover counts
     uint32_t* s_h = reinterpret_cast<uint32_t*>(s_all + nd);           // [passes][256]
     uint32_t* s_w = s_h + passes * 256;                                // [waves + 1]
+    uint32_t* s_seg = s_w + TF_THREADS / 64 + 1;                       // [nseg + 1]
+    uint32_t* s_t0 = s_seg + 260;                                      // [nseg + 1]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < nd; i += TF_THREADS) s_c[i] = diff[i];
     for (int i = tid; i < passes * 256; i += TF_THREADS) s_h[i] = 0;
@@ -526,6 +532,7 @@ __global__ void __launch_bounds__(TF_THREADS) tile_finish_kernel(int gx, int gy,
     for (int t = t0; t < t1; ++t) {
         const uint32_t c = (uint32_t)s_c[(t / gx) * pitch + (t % gx)];
         ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);
+        if (seg_start && (t & ((1 << lowbits) - 1)) == 0) s_seg[t >> lowbits] = start;
         if (c) {
             for (int p = 0; p < passes; ++p) {
                 int shift, bits;
@@ -537,10 +544,39 @@ __global__ void __launch_bounds__(TF_THREADS) tile_finish_kernel(int gx, int gy,
     }
     __syncthreads();
     for (int i = tid; i < passes * 256; i += TF_THREADS) ghist[i] = s_h[i];
+    if (!seg_start) return;
+    uint32_t all = 0;
+    for (int k = 0; k < TF_THREADS / 64; ++k) all += s_w[k];
+    for (int h = tid; h <= nseg; h += TF_THREADS)
+        if ((h << lowbits) >= ntiles) s_seg[h] = all;  // segments past the last tile are empty
+    __syncthreads();
+    if (w == 0) {
+        const int per = (nseg + 63) / 64;
+        uint32_t cnt = 0;
+        for (int k = 0; k < per; ++k) {
+            const int h = lane * per + k;
+            if (h < nseg) cnt += (s_seg[h + 1] - s_seg[h] + SORT_TILE - 1) / SORT_TILE;
+        }
+        uint32_t run = wave_scan_incl_u32(cnt) - cnt;
+        for (int k = 0; k < per; ++k) {
+            const int h = lane * per + k;
+            if (h < nseg) {
+                s_t0[h] = run;
+                run += (s_seg[h + 1] - s_seg[h] + SORT_TILE - 1) / SORT_TILE;
+            }
+            if (h == nseg - 1) s_t0[nseg] = run;
+        }
+    }
+    __syncthreads();
+    for (int h = tid; h <= nseg; h += TF_THREADS) {
+        seg_start[h] = s_seg[h];
+        seg_tile0[h] = s_t0[h];
+    }
 }
 
 hipError_t launch_tile_ranges_from_rects(const GeomBuf& g, int P, int W, int H, const ImageView& im, uint32_t* ghist,
-                                         int passes, int nbits, hipStream_t st) {
+                                         int passes, int nbits, hipStream_t st, int lowbits, uint32_t* seg_start,
+                                         uint32_t* seg_tile0) {
     const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
     const size_t nd = (size_t)(gx + 1) * (gy + 1);
     hipError_t e = hipMemsetAsync(im.tile_diff, 0, nd * sizeof(int), st);
@@ -555,7 +591,7 @@ hipError_t launch_tile_ranges_from_rects(const GeomBuf& g, int P, int W, int H, 
     const int blocks = min(TC_BLOCKS, (P + TC_THREADS - 1) / TC_THREADS);
     hipLaunchKernelGGL(tile_count_kernel, dim3(blocks), dim3(TC_THREADS), lds_c, st, P, g.bin, gx, gy, im.tile_diff);
     hipLaunchKernelGGL(tile_finish_kernel, dim3(1), dim3(TF_THREADS), lds_f, st, gx, gy, im.tile_diff, im.ranges, ghist,
-                       passes, nbits);
+                       passes, nbits, lowbits, seg_start ? 1 << (nbits - lowbits) : 0, seg_start, seg_tile0);
     return hipGetLastError();
 }
 
@@ -666,6 +702,12 @@ hipError_t launch_depth_order(const GeomBuf& g, int P, int n, hipStream_t st, in
     uint32_t* k[2] = {g.dkeys[0], g.dkeys[1]};
     uint32_t* v[2] = {g.dvals[0], g.dvals[1]};
     return launch_radix_sort_u32(k, v, n, 0, 32, g.dsort_temp, st, order_buffer, false);
+}
+
+hipError_t launch_order_gather(const GeomBuf& g, const uint32_t* order, int n, hipStream_t st) {
+    const int nb = (n + PRE_BLOCK - 1) / PRE_BLOCK;
+    hipLaunchKernelGGL(order_gather_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, n, order, g.bin, g.sbin, g.order_sums);
+    return hipGetLastError();
 }
 
 hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, const uint32_t* order, int n, uint32_t* keys,

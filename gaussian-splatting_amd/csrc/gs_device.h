@@ -385,6 +385,14 @@ inline SortTemp sort_temp_view(void* base, size_t n, int passes) {
     return v;
 }
 
+// Temp area of the emission that partitions and the segmented pass after it, behind the header of the plain
+// sort's temp area: up to 256 status words per chunk of 2048 instances, 256 per sort tile (up to 256 segments
+// each end in a partly filled tile), two words per chunk for the chunk -> Gaussian block table.
+inline size_t fused_sort_temp_bytes(size_t R) {
+    const size_t header = sort_temp_view(nullptr, 1, 0).bytes;
+    return header + ((R / 2048 + 2) + (R / SORT_TILE + 258)) * 256 * sizeof(uint32_t) + (R / 2048 + 3) * 2 * sizeof(uint32_t) + 512;
+}
+
 struct BinView {
     uint32_t* keys[2];  // tile id of each instance, ping-pong
     uint32_t* vals[2];  // Gaussian index of each instance, ping-pong
@@ -402,7 +410,8 @@ inline BinView bin_view(void* base, size_t R) {
     v.keys[1] = (uint32_t*)take(n * sizeof(uint32_t));
     v.vals[0] = (uint32_t*)take(n * sizeof(uint32_t));
     v.vals[1] = (uint32_t*)take(n * sizeof(uint32_t));
-    v.sort_temp = take(sort_temp_view(nullptr, n, SORT_MAX_PASSES).bytes);
+    const size_t plain = sort_temp_view(nullptr, n, SORT_MAX_PASSES).bytes, fused = fused_sort_temp_bytes(n);
+    v.sort_temp = take(plain > fused ? plain : fused);
     v.bytes = off;
     return v;
 }

@@ -92,7 +92,21 @@ uint32_t* sort_prepare(void* temp, int64_t n, int passes, hipStream_t st, hipErr
 // tile grid fits the LDS of one workgroup: tile_counts_fit).
 bool tile_counts_fit(int W, int H, int passes);
 hipError_t launch_tile_ranges_from_rects(const GeomBuf& g, int P, int W, int H, const ImageView& im, uint32_t* ghist,
-                                         int passes, int nbits, hipStream_t st);
+                                         int passes, int nbits, hipStream_t st, int lowbits = 0,
+                                         uint32_t* seg_start = nullptr, uint32_t* seg_tile0 = nullptr);
+// The tile rectangles in depth order (g.sbin) for the emission that follows.
+hipError_t launch_order_gather(const GeomBuf& g, const uint32_t* order, int n, hipStream_t st);
+// Key emission and instance sort in two kernels for two-digit tile ids (see radix_sort.hip): the emission
+// partitions the instances by the high digit (into keys[1] / vals[1]), one segmented pass orders them by the low
+// digit (into keys[0] / vals[0]).  fused_sort_fits: whether the sort's temp area is large enough for it;
+// fused_sort_prepare zeroes what it needs there and returns the two segment tables for tile_finish.
+bool fused_sort_fits(int64_t R, int n_visible, int nbits);
+hipError_t fused_sort_prepare(void* temp, int64_t R, int n_visible, int nbits, hipStream_t st, uint32_t** ghist,
+                              uint32_t** seg_start, uint32_t** seg_tile0);
+hipError_t launch_emit_partition(const GeomBuf& g, int n_visible, int grid_x, int nbits, int64_t R, uint32_t* keys[2],
+                                 uint32_t* vals[2], void* temp, hipStream_t st);
+hipError_t launch_segmented_pass(int n_visible, int ntiles, int nbits, int64_t R, const uint2* ranges, uint32_t* keys[2],
+                                 uint32_t* vals[2], void* temp, hipStream_t st);
 // The same with 32-bit keys.  hist_ready: the digit histograms in the temp area were filled by the caller.
 hipError_t launch_radix_sort_u32(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit,
                                  void* temp, hipStream_t st, int* result_buffer, bool hist_ready);

@@ -108,11 +108,23 @@ __device__ __forceinline__ uint32_t block_scan_excl_256_nw(uint32_t v, uint32_t*
 #ifndef GS_OS_BLOCKS
 #define GS_OS_BLOCKS 2
 #endif
-template <class K, int THREADS, int ITEMS, int BITS>
+// SEG: the input is already partitioned into segments by the key bits above `bits` (the key
+// emission does that), and the pass orders each segment on its own: workgroup tiles do not
+// straddle segments (seg.tile0[s] is the first tile of segment s, seg.start[s] its first
+// pair), the look-back ends at the first tile of the segment, and the place of digit d of
+// segment s in the output is where the tile range of tile id (s << bits) + d starts.
+struct SegArgs {
+    const uint32_t* start;  // [nseg + 1] first pair of each segment; start[nseg] = n
+    const uint32_t* tile0;  // [nseg + 1] first workgroup tile of each segment; tile0[nseg] = tiles in all
+    const uint2* ranges;    // [ntiles] tile ranges (x = first instance of the tile)
+    int nseg, ntiles;
+};
+
+template <class K, int THREADS, int ITEMS, int BITS, bool SEG>
 __global__ void __launch_bounds__(THREADS, (GS_OS_BLOCKS * THREADS) / 256)
 onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __restrict__ kout,
                 uint32_t* __restrict__ vout, int64_t n, int shift, int bits, const uint32_t* __restrict__ gbase,
-                uint32_t* status, uint32_t* ticket, uint32_t* err) {
+                uint32_t* status, uint32_t* ticket, uint32_t* err, const SegArgs seg) {
     constexpr int NW = THREADS / 64;
     constexpr int TILE = THREADS * ITEMS;
     constexpr bool ONE_PHASE = sizeof(K) == 4;  // keys and values fit the staging area together
@@ -132,7 +144,20 @@ onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* 
     for (int i = tid; i < (NW + 1) * 256; i += THREADS) s_whist[i] = 0;  // counters and s_hist
     __syncthreads();
     const uint32_t tile = *s_tile;
-    const int64_t tile_base = (int64_t)tile * TILE;
+    int64_t tile_base = (int64_t)tile * TILE;
+    bool first_tile = tile == 0;
+    uint32_t my_seg = 0;
+    if (SEG) {
+        if (tile >= seg.tile0[seg.nseg]) return;  // the grid is an upper bound of the tiles there are
+        for (int i = tid; i < seg.nseg; i += THREADS)
+            if (seg.tile0[i] <= tile && tile < seg.tile0[i + 1]) s_tile[1] = (uint32_t)i;
+        __syncthreads();
+        my_seg = s_tile[1];
+        const uint32_t t0 = seg.tile0[my_seg];
+        first_tile = tile == t0;
+        tile_base = (int64_t)seg.start[my_seg] + (int64_t)(tile - t0) * TILE;
+        n = seg.start[my_seg + 1];
+    }
     const int64_t wave_base = tile_base + (int64_t)w * (64 * ITEMS);
     const uint32_t dmask = (1u << bits) - 1;
 
@@ -158,7 +183,7 @@ onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* 
     const uint32_t dcount = dthread ? s_hist[tid] : 0u;
     uint32_t* const my = status + (size_t)tile * 256 + tid;
     if (dthread)
-        __hip_atomic_store(my, dcount | (tile == 0 ? ST_INCL : ST_AGG), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(my, dcount | (first_tile ? ST_INCL : ST_AGG), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t tile_total;
     const uint32_t dstart = block_scan_excl_256_nw<NW>(dcount, s_tmp, &tile_total);
     if (dthread) s_dstart[tid] = dstart;
@@ -206,7 +231,7 @@ onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* 
     // 3. Decoupled look-back for digit `tid`, LOOK_BATCH predecessors per round trip.
     if (dthread) {
         uint32_t excl = 0;
-        if (tile > 0) {
+        if (!first_tile) {
             int64_t look = (int64_t)tile - 1;
             uint32_t spins = 0;
             bool done = false;
@@ -241,7 +266,14 @@ onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* 
             }
             __hip_atomic_store(my, ((excl + dcount) & ST_MASK) | ST_INCL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        s_gofs[tid] = gbase[tid] + excl - dstart;
+        uint32_t base;
+        if (SEG) {
+            const uint32_t t = (my_seg << bits) + (uint32_t)tid;
+            base = (tid < (1 << bits) && t < (uint32_t)seg.ntiles) ? seg.ranges[t].x : 0u;
+        } else {
+            base = gbase[tid];
+        }
+        s_gofs[tid] = base + excl - dstart;
     }
     __syncthreads();
 
@@ -288,6 +320,274 @@ onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* 
     }
 }
 
+// ------------------------------------------------------------------ key emission that partitions
+// duplicateWithKeys (rasterizer_impl.cu:70-110) and the first half of the sort in one kernel.
+// The Gaussians come in depth order, so their instances only have to be brought into tile
+// order stably.  Instead of storing the instances in emission order for a radix pass to read
+// back, every 4096 consecutive ones are generated straight into the registers of a workgroup
+// and treated as one tile of a radix pass on the HIGH digit of the tile id: chunk histogram
+// published at once, stable ranks from ballots, decoupled look-back over the chunks before it,
+// coalesced stores through LDS into the segment of that digit, whose place is known
+// beforehand from the tile counts.  What is left is one pass on the low digit inside each
+// segment (onesweep_kernel<SEG>).
+//
+// Work is dealt by instances, not by Gaussians: in depth order the first Gaussians are the
+// nearest and largest, and a workgroup that owned a fixed number of them would emit for a
+// millisecond while the rest of the GPU idles.  chunk_first[c] is the block of 256 Gaussians
+// in which instance c * 4096 falls; the chunk's Gaussians (at most 4096 + 1, i.e. seventeen
+// blocks; typically two or three) get their running instance offsets into LDS, and each
+// instance finds its Gaussian there by binary search.
+#ifndef GS_EP_THREADS
+#define GS_EP_THREADS 512
+#endif
+constexpr int EP_THREADS = GS_EP_THREADS;
+constexpr int EP_ITEMS = 8;
+constexpr int EP_CHUNK = EP_THREADS * EP_ITEMS;  // instances per chunk
+constexpr int EP_MAX_BLOCKS = EP_CHUNK / 256 + 1;
+constexpr int EP_MAX_PER = (EP_MAX_BLOCKS * 256 + EP_THREADS - 1) / EP_THREADS;
+static_assert(EP_CHUNK >= 2048, "fused_sort_temp_bytes sizes the chunk tables for chunks of at least 2048");
+
+// Exclusive scan over all threads of a block of NW waves.
+template <int NW>
+__device__ __forceinline__ uint32_t block_scan_excl_nw(uint32_t v, uint32_t* tmp, uint32_t* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t incl = wave_scan_incl_u32(v);
+    if (lane == 63) tmp[w] = incl;
+    __syncthreads();
+    uint32_t base = 0, sum = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const uint32_t t = tmp[i];
+        if (i < w) base += t;
+        sum += t;
+    }
+    __syncthreads();
+    *total = sum;
+    return base + incl - v;
+}
+
+struct EmitPartArgs {
+    const uint4* sbin;            // [n] {x0 | y0<<16, w | h<<16, Gaussian index, tiles} in depth order
+    const uint32_t* offs;         // [nb256 + 1] exclusive instance offsets per block of 256 of them
+    const uint2* chunk_first;     // [chunks + 1] block in which the chunk's first instance falls, that block's offset
+    int n, nb256, grid_x, lowbits;
+    uint32_t R;
+    const uint32_t* seg_start;    // [nseg + 1]
+    uint32_t* status;             // [chunks][nseg]
+    uint32_t* ticket;
+    uint32_t* err;
+    uint32_t* kout;
+    uint32_t* vout;
+};
+
+__global__ void __launch_bounds__(256) chunk_map_kernel(int nb256, const uint32_t* __restrict__ offs,
+                                                        uint2* __restrict__ chunk_first, uint32_t chunks) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nb256) return;
+    const uint32_t s0 = offs[b], s1 = offs[b + 1];
+    for (uint32_t c = (s0 + EP_CHUNK - 1) / EP_CHUNK; (uint64_t)c * EP_CHUNK < s1; ++c)
+        chunk_first[c] = make_uint2((uint32_t)b, s0);
+    if (b == nb256 - 1) chunk_first[chunks] = make_uint2((uint32_t)b, s0);  // "the chunk after the last" starts in the last block
+}
+
+template <int HB>
+__global__ void __launch_bounds__(EP_THREADS) emit_partition_kernel(const EmitPartArgs a) {
+    constexpr int NB = 1 << HB;  // segments = values of the high digit
+    constexpr int NW = EP_THREADS / 64;
+    __shared__ uint32_t s_off[EP_MAX_BLOCKS * 256 + 1];
+    __shared__ uint32_t s_keys[EP_CHUNK];
+    __shared__ uint32_t s_vals[EP_CHUNK];
+    __shared__ uint32_t s_whist[NW * NB + NB];  // per-wave counters, then the chunk histogram
+    __shared__ uint32_t s_dstart[NB];
+    __shared__ uint32_t s_gofs[NB];
+    __shared__ uint32_t s_tmp[8];
+    __shared__ uint32_t s_chunk;
+    uint32_t* const s_hist = s_whist + NW * NB;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_chunk = atomicAdd(a.ticket, 1u);
+    for (int i = tid; i < (NW + 1) * NB; i += EP_THREADS) s_whist[i] = 0;
+    __syncthreads();
+    const uint32_t chunk = s_chunk;
+    const uint32_t i0 = chunk * EP_CHUNK;             // first instance of the chunk
+    const uint32_t chunk_n = min((uint32_t)EP_CHUNK, a.R - i0);
+    const uint32_t i1 = i0 + chunk_n;
+    // The chunk's Gaussians: those of the block its first instance falls in up to the block in which
+    // the next chunk starts (one more than needed when that one starts exactly at a block boundary;
+    // its entries are then never chosen).  Their running instance offsets go to LDS: every thread
+    // sums `per` consecutive tile counts, one scan over the threads' sums gives the rest.
+    const uint2 cf = a.chunk_first[chunk], cf_next = a.chunk_first[chunk + 1];
+    const int b0 = (int)cf.x;
+    const int nblk = min((int)cf_next.x - b0 + 1, EP_MAX_BLOCKS);
+    const int cnt = nblk * 256;  // entries of s_off
+    {
+        const int per = (cnt + EP_THREADS - 1) / EP_THREADS;
+        uint32_t tl[EP_MAX_PER];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < EP_MAX_PER; ++j) {
+            const int e = tid * per + j;
+            const int g = b0 * 256 + e;
+            tl[j] = (j < per && e < cnt && g < a.n) ? a.sbin[g].w : 0u;
+            mine += tl[j];
+        }
+        uint32_t total;
+        uint32_t ex = cf.y + block_scan_excl_nw<NW>(mine, s_tmp, &total);
+#pragma unroll
+        for (int j = 0; j < EP_MAX_PER; ++j) {
+            const int e = tid * per + j;
+            if (j < per && e < cnt) s_off[e] = ex;
+            ex += tl[j];
+        }
+        if (tid == 0) s_off[cnt] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    const int top = 1 << (31 - __builtin_clz((unsigned)cnt));  // cnt >= 256
+
+    uint32_t key[EP_ITEMS], val[EP_ITEMS], rank[EP_ITEMS];
+    const uint32_t hmask = NB - 1;
+    // a. the instances of the chunk, wave-striped: item k of lane l in wave w is number w * 512 + k * 64 + l.
+    //    The eight searches of a lane advance together, one LDS read each per step.
+    int lo[EP_ITEMS];  // largest entry with s_off[entry] <= the instance's number
+#pragma unroll
+    for (int k = 0; k < EP_ITEMS; ++k) lo[k] = 0;
+#pragma unroll 1
+    for (int step = top; step >= 1; step >>= 1) {
+#pragma unroll
+        for (int k = 0; k < EP_ITEMS; ++k) {
+            const uint32_t sidx = i0 + (uint32_t)(w * (64 * EP_ITEMS) + k * 64 + lane);
+            const int probe = min(lo[k] + step, cnt);  // s_off[cnt] is the all-ones sentinel
+            if (s_off[probe] <= sidx) lo[k] = probe;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < EP_ITEMS; ++k) {
+        const uint32_t q0 = (uint32_t)(w * (64 * EP_ITEMS) + k * 64 + lane);
+        key[k] = 0xFFFFFFFFu;
+        val[k] = 0u;
+        if (q0 < chunk_n) {
+            const uint32_t sidx = i0 + q0;
+            const uint4 gb = a.sbin[b0 * 256 + lo[k]];
+            const uint32_t q = sidx - s_off[lo[k]];
+            const uint32_t rw = gb.y & 0xffffu;
+            const uint32_t ty = q / rw;
+            const uint32_t tx = q - ty * rw;
+            key[k] = ((gb.x >> 16) + ty) * (uint32_t)a.grid_x + (gb.x & 0xffffu) + tx;
+            val[k] = gb.z;
+        }
+    }
+    // b. chunk histogram of the high digit, published at once
+#pragma unroll
+    for (int k = 0; k < EP_ITEMS; ++k) {
+        const uint32_t q0 = (uint32_t)(w * (64 * EP_ITEMS) + k * 64 + lane);
+        if (q0 < chunk_n) atomicAdd(&s_hist[(key[k] >> a.lowbits) & hmask], 1u);
+    }
+    __syncthreads();
+    const bool dthread = tid < NB;
+    const uint32_t dcount = dthread ? s_hist[tid] : 0u;
+    uint32_t* const my = a.status + (size_t)chunk * NB + tid;
+    if (dthread)
+        __hip_atomic_store(my, dcount | (chunk == 0 ? ST_INCL : ST_AGG), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t chunk_total;
+    const uint32_t dstart = block_scan_excl_nw<NW>(dcount, s_tmp, &chunk_total);
+    if (dthread) s_dstart[tid] = dstart;
+    // c. stable ranks inside the wave
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
+    lds_u32* const wh = (lds_u32*)(s_whist + w * NB);
+#pragma unroll
+    for (int k = 0; k < EP_ITEMS; ++k) {
+        const uint32_t q0 = (uint32_t)(w * (64 * EP_ITEMS) + k * 64 + lane);
+        const bool ok = q0 < chunk_n;
+        const uint32_t d = (key[k] >> a.lowbits) & hmask;
+        const uint64_t okm = __builtin_amdgcn_ballot_w64(ok);
+        uint32_t plo = (uint32_t)okm, phi = (uint32_t)(okm >> 32);
+#pragma unroll
+        for (int bit = 0; bit < HB; ++bit) {
+            uint32_t m = (uint32_t)(((int32_t)(d << (31 - bit))) >> 31);
+            asm("" : "+v"(m));
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(m != 0);
+            plo &= ~((uint32_t)bal ^ m);
+            phi &= ~((uint32_t)(bal >> 32) ^ m);
+        }
+        const uint32_t lower = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+        const uint32_t cnt_same = __popc(plo) + __popc(phi);
+        const uint32_t prev = wh[d];
+        if (ok && lower == 0) wh[d] = prev + cnt_same;
+        rank[k] = prev + lower;
+    }
+    __syncthreads();
+    if (dthread) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const uint32_t cw = s_whist[i * NB + tid];
+            s_whist[i * NB + tid] = run;
+            run += cw;
+        }
+        // d. decoupled look-back over the chunks before this one
+        uint32_t excl = 0;
+        if (chunk > 0) {
+            int64_t look = (int64_t)chunk - 1;
+            uint32_t spins = 0;
+            bool done = false;
+            while (!done) {
+                uint32_t v[LOOK_BATCH];
+#pragma unroll
+                for (int i = 0; i < LOOK_BATCH; ++i) {
+                    const int64_t t = look - i;
+                    v[i] = t >= 0 ? __hip_atomic_load(a.status + (size_t)t * NB + tid, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT)
+                                  : ST_INCL;
+                }
+#pragma unroll
+                for (int i = 0; i < LOOK_BATCH; ++i) {
+                    if (done) break;
+                    const uint32_t flag = v[i] & ~ST_MASK;
+                    if (flag == 0) {  // not published yet: poll again from this chunk
+                        look -= i;
+                        if (++spins > SPIN_LIMIT) {
+                            atomicOr(a.err, 1u);
+                            done = true;
+                        } else {
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        goto next_round;
+                    }
+                    excl += v[i] & ST_MASK;
+                    if (flag == ST_INCL) done = true;
+                }
+                look -= LOOK_BATCH;
+            next_round:;
+            }
+            __hip_atomic_store(my, ((excl + dcount) & ST_MASK) | ST_INCL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_gofs[tid] = a.seg_start[tid] + excl - dstart;
+    }
+    __syncthreads();
+    // e. through LDS in segment order, then out
+#pragma unroll
+    for (int k = 0; k < EP_ITEMS; ++k) {
+        const uint32_t q0 = (uint32_t)(w * (64 * EP_ITEMS) + k * 64 + lane);
+        if (q0 < chunk_n) {
+            const uint32_t d = (key[k] >> a.lowbits) & hmask;
+            const uint32_t slot = s_dstart[d] + s_whist[w * NB + d] + rank[k];
+            s_keys[slot] = key[k];
+            s_vals[slot] = val[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EP_ITEMS; ++k) {
+        const uint32_t pos = (uint32_t)(tid + k * EP_THREADS);
+        if (pos < chunk_n) {
+            const uint32_t kk = s_keys[pos];
+            const uint32_t dst = s_gofs[(kk >> a.lowbits) & hmask] + pos;
+            a.kout[dst] = kk;
+            a.vout[dst] = s_vals[pos];
+        }
+    }
+}
+
 #ifndef GS_OS_THREADS
 #define GS_OS_THREADS 512
 #endif
@@ -322,18 +622,137 @@ hipError_t radix_sort_impl(K* keys[2], uint32_t* vals[2], int64_t n, int begin_b
         int shift, bits;
         digit_of_pass(end_bit - begin_bit, passes, p, &shift, &bits);
         // u32 keys (the rasterizer's two sorts) have kernels for 6-, 7- and 8-bit digits
-        auto kern = onesweep_kernel<K, OS_THREADS, OS_ITEMS, 8>;
-        if (sizeof(K) == 4 && bits <= 6) kern = onesweep_kernel<K, OS_THREADS, OS_ITEMS, sizeof(K) == 4 ? 6 : 8>;
-        else if (sizeof(K) == 4 && bits == 7) kern = onesweep_kernel<K, OS_THREADS, OS_ITEMS, sizeof(K) == 4 ? 7 : 8>;
+        auto kern = onesweep_kernel<K, OS_THREADS, OS_ITEMS, 8, false>;
+        if (sizeof(K) == 4 && bits <= 6) kern = onesweep_kernel<K, OS_THREADS, OS_ITEMS, sizeof(K) == 4 ? 6 : 8, false>;
+        else if (sizeof(K) == 4 && bits == 7) kern = onesweep_kernel<K, OS_THREADS, OS_ITEMS, sizeof(K) == 4 ? 7 : 8, false>;
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)OS_LDS);
         if (ea != hipSuccess) return ea;
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(OS_THREADS), OS_LDS, st, keys[cur], vals[cur],
                            keys[cur ^ 1], vals[cur ^ 1], n, begin_bit + shift, bits, t.ghist + p * 256,
-                           t.status + (size_t)p * tiles * 256, t.ticket + p, t.err);
+                           t.status + (size_t)p * tiles * 256, t.ticket + p, t.err, SegArgs());
         cur ^= 1;
     }
     *result_buffer = cur;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ emission + segmented pass
+namespace {
+struct FusedTemp {
+    uint32_t *ghist, *seg_start, *seg_tile0, *ticket, *err, *status_a, *status_b, *chunk_first;
+    size_t zero_bytes;
+};
+
+FusedTemp fused_temp_view(void* temp, int64_t R, int n_visible, int nbits) {
+    // the header of the plain sort's temp area (histograms, tickets, error word), then the status words
+    const SortTemp t = sort_temp_view(temp, 1, 0);
+    const size_t header = sort_temp_view(nullptr, 1, 0).bytes;
+    int lowshift, lowbits;
+    digit_of_pass(nbits, 2, 0, &lowshift, &lowbits);
+    const size_t nseg = (size_t)1 << (nbits - lowbits);
+    const size_t chunks = ((size_t)R + EP_CHUNK - 1) / EP_CHUNK;
+    const size_t words_a = align_up(chunks * nseg + 1, 64);
+    const size_t words_b = ((size_t)R / SORT_TILE + nseg + 2) * 256;
+    (void)n_visible;
+    FusedTemp f;
+    f.ghist = t.ghist;
+    f.seg_start = temp ? t.ghist + 1024 : nullptr;  // [nseg + 1] each, in the part of the histogram area two passes leave free
+    f.seg_tile0 = temp ? t.ghist + 1536 : nullptr;
+    f.ticket = t.ticket;
+    f.err = t.err;
+    f.status_a = temp ? (uint32_t*)((char*)temp + header) : nullptr;
+    f.status_b = temp ? f.status_a + words_a : nullptr;
+    f.chunk_first = temp ? f.status_b + words_b : nullptr;  // [chunks + 1] pairs, written before they are read: outside the zeroed part
+    f.zero_bytes = header + (words_a + words_b) * sizeof(uint32_t);
+    return f;
+}
+}  // namespace
+
+bool fused_sort_fits(int64_t R, int n_visible, int nbits) {
+    if (R <= 0 || n_visible <= 0 || sort_passes_for(0, nbits) != 2) return false;
+    int lowshift, lowbits;
+    digit_of_pass(nbits, 2, 0, &lowshift, &lowbits);
+    const int hb = nbits - lowbits;
+    if (hb < 1 || hb > 8 || (int64_t)n_visible > R) return false;
+    return fused_temp_view(nullptr, R, n_visible, nbits).zero_bytes + (R / EP_CHUNK + 3) * sizeof(uint2) <=
+           fused_sort_temp_bytes((size_t)R);
+}
+
+hipError_t fused_sort_prepare(void* temp, int64_t R, int n_visible, int nbits, hipStream_t st, uint32_t** ghist,
+                              uint32_t** seg_start, uint32_t** seg_tile0) {
+    const FusedTemp f = fused_temp_view(temp, R, n_visible, nbits);
+    *ghist = f.ghist;
+    *seg_start = f.seg_start;
+    *seg_tile0 = f.seg_tile0;
+    return hipMemsetAsync(f.ghist, 0, f.zero_bytes, st);
+}
+
+hipError_t launch_emit_partition(const GeomBuf& g, int n_visible, int grid_x, int nbits, int64_t R, uint32_t* keys[2],
+                                 uint32_t* vals[2], void* temp, hipStream_t st) {
+    const FusedTemp f = fused_temp_view(temp, R, n_visible, nbits);
+    int lowshift, lowbits;
+    digit_of_pass(nbits, 2, 0, &lowshift, &lowbits);
+    const int hb = nbits - lowbits;
+    const int nb256 = (n_visible + PRE_BLOCK - 1) / PRE_BLOCK;
+    const unsigned chunks = (unsigned)((R + EP_CHUNK - 1) / EP_CHUNK);
+    // instance offsets per block of 256 Gaussians (g.total was read by the host already; the scan rewrites the same values)
+    hipError_t e0 = launch_scan_u32(g.order_sums, nb256, g.total, st);
+    if (e0 != hipSuccess) return e0;
+    hipLaunchKernelGGL(chunk_map_kernel, dim3((nb256 + 255) / 256), dim3(256), 0, st, nb256, g.order_sums,
+                       reinterpret_cast<uint2*>(f.chunk_first), chunks);
+    EmitPartArgs a;
+    a.sbin = g.sbin;
+    a.offs = g.order_sums;
+    a.chunk_first = reinterpret_cast<const uint2*>(f.chunk_first);
+    a.n = n_visible;
+    a.nb256 = nb256;
+    a.grid_x = grid_x;
+    a.lowbits = lowbits;
+    a.R = (uint32_t)R;
+    a.seg_start = f.seg_start;
+    a.status = f.status_a;
+    a.ticket = f.ticket;
+    a.err = f.err;
+    a.kout = keys[1];
+    a.vout = vals[1];
+    const dim3 grid(chunks), block(EP_THREADS);
+    switch (hb) {
+        case 1: hipLaunchKernelGGL(emit_partition_kernel<1>, grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(emit_partition_kernel<2>, grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL(emit_partition_kernel<3>, grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL(emit_partition_kernel<4>, grid, block, 0, st, a); break;
+        case 5: hipLaunchKernelGGL(emit_partition_kernel<5>, grid, block, 0, st, a); break;
+        case 6: hipLaunchKernelGGL(emit_partition_kernel<6>, grid, block, 0, st, a); break;
+        case 7: hipLaunchKernelGGL(emit_partition_kernel<7>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(emit_partition_kernel<8>, grid, block, 0, st, a); break;
+    }
+    return hipGetLastError();
+}
+
+// The low digit inside each segment: keys[1] -> keys[0].
+hipError_t launch_segmented_pass(int n_visible, int ntiles, int nbits, int64_t R, const uint2* ranges, uint32_t* keys[2],
+                                 uint32_t* vals[2], void* temp, hipStream_t st) {
+    const FusedTemp f = fused_temp_view(temp, R, n_visible, nbits);
+    int lowshift, lowbits;
+    digit_of_pass(nbits, 2, 0, &lowshift, &lowbits);
+    const int hb = nbits - lowbits;
+    SegArgs seg;
+    seg.start = f.seg_start;
+    seg.tile0 = f.seg_tile0;
+    seg.ranges = ranges;
+    seg.nseg = 1 << hb;
+    seg.ntiles = ntiles;
+    auto kern = onesweep_kernel<uint32_t, OS_THREADS, OS_ITEMS, 8, true>;
+    if (lowbits <= 6) kern = onesweep_kernel<uint32_t, OS_THREADS, OS_ITEMS, 6, true>;
+    else if (lowbits == 7) kern = onesweep_kernel<uint32_t, OS_THREADS, OS_ITEMS, 7, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)OS_LDS);
+    if (e != hipSuccess) return e;
+    const unsigned tiles = (unsigned)(R / SORT_TILE + seg.nseg + 1);  // an upper bound; the kernel knows the number
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(OS_THREADS), OS_LDS, st, (const uint32_t*)keys[1],
+                       (const uint32_t*)vals[1], keys[0], vals[0], R, 0, lowbits, (const uint32_t*)nullptr, f.status_b,
+                       f.ticket + 1, f.err, seg);
     return hipGetLastError();
 }
 
