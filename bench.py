@@ -168,7 +168,8 @@ def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1, walked=None, from_
         # the digit histograms and the tile ranges come from the tile rectangles (16 B per Gaussian) when the
         # tile grid fits one workgroup's LDS; otherwise from a histogram sweep and a range scan over the keys
         "tile_count": P * 16.0 if from_rects else None,
-        "sort": R * ((0.0 if from_rects else 4.0) + passes * 16.0),
+        # two-digit tile ids with rectangle counts: the emission partitions by the high digit, one pass is left
+        "sort": R * ((0.0 if from_rects else 4.0) + (1 if from_rects and passes == 2 else passes) * 16.0),
         "tile_ranges": None if from_rects else 4.0 * R,
         "render_fwd": 28.0 * walked + 48.0 * HW,
         "render_bwd": 60.0 * walked + 40.0 * HW + 56.0 * walked,
@@ -582,7 +583,8 @@ def main():
             # the reference's sort (R pairs of u64 key + u32 value) is done here by the depth ordering of the
             # Gaussians plus the sort of the instances on their tile id: payload rate over both
             "sort_GBps": (R * 12.0 / ((kernels["sort"] + kernels["depth_order"]) * 1e-3) / 1e9) if R else None,
-            "sort_hbm_GBps": (R * ((0.0 if from_rects else 4.0) + passes * 16.0) / (kernels["sort"] * 1e-3) / 1e9) if R else None,
+            "sort_hbm_GBps": (algorithmic_bytes("sort", P, visible, R, H * W, passes, V, walked, from_rects) /
+                              (kernels["sort"] * 1e-3) / 1e9) if R else None,
         }
         if overlapping:
             res["kernels_in_timed_region_ms"] = kernels_overlapped

@@ -21,7 +21,7 @@ KERNEL_KEYS = {  # kernel symbol substring -> bench.py kernel name
     "sort_scan_hist_kernel": "sort:scan", "tile_ranges_kernel": "tile_ranges", "render_fwd_kernel": "render_fwd",
     "render_bwd_kernel": "render_bwd", "preprocess_bwd_kernel": "preprocess_bwd",
     "preprocess_bwd_batch_kernel": "preprocess_bwd_batch", "preprocess_fwd_batch_kernel": "preprocess_batch", "order_gather_kernel": "depth_order:gather", "ssim_fwd": "ssim_fwd",
-    "ssim_bwd": "ssim_bwd", "scan_blocks_kernel": "scan", "finish_gstat_kernel": "finish_stats", "clear_reached_kernel": "bwd_clear", "tile_count_kernel": "tile_count:count", "tile_finish_kernel": "tile_count:finish"}
+    "ssim_bwd": "ssim_bwd", "scan_blocks_kernel": "scan", "finish_gstat_kernel": "finish_stats", "clear_reached_kernel": "bwd_clear", "tile_count_kernel": "tile_count:count", "tile_finish_kernel": "tile_count:finish", "emit_partition_kernel": "emit_keys", "chunk_map_kernel": "emit:chunk_map"}
 
 
 def short(name, grid=0):
@@ -39,7 +39,7 @@ def short(name, grid=0):
 # bench.py kernel name -> (detail name, launches per view) that make it up
 COMPOSED = {
     # "sort:hist" only when the tile grid is too large for the rectangle-count path (then "tile_count" is absent)
-    "sort": (("sort:hist", 1), ("sort:scan", 1), ("sort:onesweep", 2)),
+    "sort": (("sort:hist", 1), ("sort:scan", 1), ("sort:onesweep", 1)),
     "tile_count": (("tile_count:count", 1), ("tile_count:finish", 1)),
     "depth_order": (("depth_order:keys", 1), ("depth_order:hist", 1), ("depth_order:onesweep", 4)),
     "emit_keys": (("depth_order:gather", 1), ("emit_keys", 1)),
