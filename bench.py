@@ -302,6 +302,8 @@ def main():
     side_streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else []
     batch_fwd = use_params and not args.no_batch_forward and V > 1
 
+    host_wait = [0.0]
+
     def step(k=None, timer=None, overlap=True):
         side = side_streams if overlap else []
         if use_params:
@@ -313,7 +315,9 @@ def main():
         if batch_fwd:
             if timer is not None:
                 timer.arm(k * V)
+            tp = time.perf_counter()
             sink.prepare_views([rs for rs, _ in views])   # the forward preprocess of all V views, once
+            host_wait[0] += time.perf_counter() - tp      # the one call of a step in which the host blocks
         if len(side) > 1:
             ready = torch.cuda.Event()
             ready.record()
@@ -355,6 +359,7 @@ def main():
         out = step(0, timer)
     reducer_ms.clear()
     sync()
+    host_wait[0] = 0.0
     t0 = time.perf_counter()
     marks = []
     for k in range(args.steps):
@@ -362,6 +367,7 @@ def main():
         marks.append(time.perf_counter())   # host-side launch progress (no sync): shows when the host is the limit
     sync()
     dt = time.perf_counter() - t0
+    host_wait_ms = host_wait[0] / args.steps * 1e3
     log(f"[rank {rank}] host launch time per step (ms): " +
         " ".join(f"{(b - a) * 1e3:.1f}" for a, b in zip([t0] + marks[:-1], marks)))
     timer.arm(None)
@@ -558,6 +564,10 @@ def main():
             "unit": "frames/s" if args.fwd_only else "it/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            # of a step, the time the host spends blocked in the batched preprocess call (waiting for the GPU to
+            # get there); the rest of the step it is enqueueing: the closer this gets to zero, the closer the host
+            # is to being the limit
+            "host_blocked_ms_per_step": host_wait_ms if batch_fwd else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"street scene, {P} Gaussians SH3 + 4 reps, {W}x{H}, antialiasing; a step = {V} views "
