@@ -237,9 +237,10 @@ def main():
                     help="params: forward_params (raw parameters); reference: unchanged reference signature")
     ap.add_argument("--no-batch-forward", action="store_true",
                     help="run the forward preprocess per view instead of once per step for all its views")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams the views of a step are dealt to round-robin (kernels of different views overlap); "
-                         "1 = one view after the other")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="HIP streams the views of a step are dealt to round-robin, the current stream being one of them "
+                         "(kernels of different views overlap; 4 = the hardware queues a process has); 1 = one view "
+                         "after the other")
     ap.add_argument("--torch-loss", action="store_true",
                     help="compose the photometric loss from PyTorch operations around fused_ssim, as train.py does, "
                          "instead of fused_ssim.l1_ssim_loss (the reference-signature runs always do)")
@@ -299,13 +300,14 @@ def main():
         return out
 
     reducer_ms = []
-    side_streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else []
+    side_streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams - 1)] if args.streams > 1 else []
     batch_fwd = use_params and not args.no_batch_forward and V > 1
 
     host_wait = [0.0]
 
     def step(k=None, timer=None, overlap=True):
-        side = side_streams if overlap else []
+        # the views are dealt to the current stream and the side streams in turn
+        side = ([torch.cuda.current_stream()] + side_streams) if (overlap and side_streams) else []
         if use_params:
             sink.begin_step()
         else:
@@ -321,7 +323,7 @@ def main():
         if len(side) > 1:
             ready = torch.cuda.Event()
             ready.record()
-            for st in side:
+            for st in side[1:]:
                 st.wait_event(ready)
         for v, (rs, gt) in enumerate(views):
             if timer is not None:
@@ -332,7 +334,7 @@ def main():
             else:
                 out = one_view(rs, gt)
         if len(side) > 1:
-            for st in side:
+            for st in side[1:]:
                 torch.cuda.current_stream().wait_stream(st)
         if use_params and not args.fwd_only:
             sink.flush()   # deferred mode: the per-Gaussian backward of all V views, once
@@ -390,7 +392,7 @@ def main():
     # timed region and an event pair there spans other views' kernels too: those numbers are kept
     # (`kernels_in_timed_region_ms`), and the durations that the roofline figures use are measured, live and on
     # the same workload, in a pass with one view after the other that follows the timed region.
-    overlapping = len(side_streams) > 1
+    overlapping = len(side_streams) >= 1
     kernels_overlapped, one_stream_it_s = None, None
     if overlapping:
         kernels_overlapped = kernel_means(timer, args.steps)
@@ -486,16 +488,13 @@ def main():
                 with torch.no_grad():
                     sink.begin_step()
                     sink.prepare_views([rs for rs, _ in views])
-                    if side_streams:
-                        ready = torch.cuda.Event()
-                        ready.record()
-                        for st in side_streams:
-                            st.wait_event(ready)
+                    lanes = [torch.cuda.current_stream()] + side_streams
+                    ready = torch.cuda.Event()
+                    ready.record()
+                    for st in side_streams:
+                        st.wait_event(ready)
                     for v, (rs, _) in enumerate(views):
-                        if side_streams:
-                            with torch.cuda.stream(side_streams[v % len(side_streams)]):
-                                render_params(params, rs, sink)
-                        else:
+                        with torch.cuda.stream(lanes[v % len(lanes)]):
                             render_params(params, rs, sink)
                     for st in side_streams:
                         torch.cuda.current_stream().wait_stream(st)
@@ -575,7 +574,7 @@ def main():
                                    (", forward only" if args.fwd_only else ", each fwd + fused-ssim loss + bwd, then one "
                                     "gradient all-reduce when n_gpus > 1; no optimizer"),
                        "api": "forward_params (raw parameters)" if use_params else "reference signature",
-                       "streams": max(1, len(side_streams)),
+                       "streams": 1 + len(side_streams),
                        "loss": ("fused_ssim.l1_ssim_loss + fused_ssim.l1_loss on the reps" if fused_loss else
                                 "PyTorch L1 / clamp around fused_ssim + reps L1 (as train.py)"),
                        "gaussians": P, "views_per_gpu_per_step": V, "visible_mean": visible, "num_rendered_mean": R,

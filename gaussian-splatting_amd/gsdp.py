@@ -75,7 +75,8 @@ def run_views(sink, settings_list, loss_of_view, streams=()):
     `begin_step`, the forward preprocess of all the views in one pass, `loss_of_view(i, settings)`
     (render view i with `forward_params(..., grad_sink=sink)` and return its scalar loss) and
     `backward()` per view, then `flush()`.  With `streams` (a list of `torch.cuda.Stream`) the
-    views are dealt to them round-robin: the views are independent until the flush, and the
+    views are dealt round-robin to the current stream and to them (three side streams make four
+    lanes, the number of hardware queues a process has): the views are independent until the flush, and the
     kernels of a view leave much of the GPU idle (sort passes that wait on their look-back, the
     ramp-down of the blend kernels), so two or three views in flight finish sooner than one after
     the other.  Gradients are the same sums either way (float atomics: not bit for bit).
@@ -83,6 +84,7 @@ def run_views(sink, settings_list, loss_of_view, streams=()):
     sink.begin_step()
     sink.prepare_views(settings_list)
     main = torch.cuda.current_stream()
+    lanes = [main] + list(streams)
     if streams:
         ready = torch.cuda.Event()
         ready.record(main)
@@ -90,11 +92,7 @@ def run_views(sink, settings_list, loss_of_view, streams=()):
             st.wait_event(ready)
     losses = []
     for i, rs in enumerate(settings_list):
-        if streams:
-            with torch.cuda.stream(streams[i % len(streams)]):
-                loss = loss_of_view(i, rs)
-                loss.backward()
-        else:
+        with torch.cuda.stream(lanes[i % len(lanes)]):
             loss = loss_of_view(i, rs)
             loss.backward()
         losses.append(loss.detach())
