@@ -272,10 +272,10 @@ __global__ void __launch_bounds__(PRE_BLOCK, 2) preprocess_fwd_batch_kernel(cons
 }
 
 // Exclusive scan of the per-block sums, total instance count into total[0],
-// overflow flag into total[1].  One workgroup of 1024 threads, 16 consecutive
-// sums per thread and step, so 23 k sums (6 M Gaussians) take two steps; the
+// overflow flag into total[1].  One workgroup of 1024 threads, 32 consecutive
+// sums per thread and step (16-byte loads and stores), so 23 k sums (6 M Gaussians) take one step; the
 // running values are 64-bit so that an overflowing total is detected, not wrapped.
-constexpr int SCAN_THREADS = 1024, SCAN_ITEMS = 16;
+constexpr int SCAN_THREADS = 1024, SCAN_ITEMS = 32;
 // Workgroup 1, if launched, scans a second array the same way (the per-block
 // counts of Gaussians with instances) and writes its total into total[2].
 __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* sums0, uint32_t* sums1, int nb,
@@ -288,11 +288,22 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* sum
         const int i0 = base + tid * SCAN_ITEMS;
         uint32_t v[SCAN_ITEMS];
         uint64_t mine = 0;
+        if (i0 + SCAN_ITEMS <= nb) {  // whole 16-byte groups (the arrays start on 256-byte boundaries)
+            const uint4* src = reinterpret_cast<const uint4*>(block_sums + i0);
 #pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) {
-            v[k] = i0 + k < nb ? block_sums[i0 + k] : 0u;
-            mine += v[k];
+            for (int k = 0; k < SCAN_ITEMS / 4; ++k) {
+                const uint4 q = src[k];
+                v[4 * k] = q.x;
+                v[4 * k + 1] = q.y;
+                v[4 * k + 2] = q.z;
+                v[4 * k + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = i0 + k < nb ? block_sums[i0 + k] : 0u;
         }
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) mine += v[k];
         uint64_t incl = mine;  // inclusive scan over the wave
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -310,10 +321,27 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* sum
         }
         __syncthreads();
         uint64_t run = carry + before + incl - mine;
+        if (i0 + SCAN_ITEMS <= nb) {
+            uint4* dst = reinterpret_cast<uint4*>(block_sums + i0);
 #pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) {
-            if (i0 + k < nb) block_sums[i0 + k] = (uint32_t)run;
-            run += v[k];
+            for (int k = 0; k < SCAN_ITEMS / 4; ++k) {
+                uint4 q;
+                q.x = (uint32_t)run;
+                run += v[4 * k];
+                q.y = (uint32_t)run;
+                run += v[4 * k + 1];
+                q.z = (uint32_t)run;
+                run += v[4 * k + 2];
+                q.w = (uint32_t)run;
+                run += v[4 * k + 3];
+                dst[k] = q;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; ++k) {
+                if (i0 + k < nb) block_sums[i0 + k] = (uint32_t)run;
+                run += v[k];
+            }
         }
         carry += all;
     }
