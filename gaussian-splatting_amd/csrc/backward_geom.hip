@@ -524,17 +524,18 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
 // Zeroes the GradRecs the backward blend can add to: those of the Gaussians some pixel reached
 // in the forward.  The others are never read (see `rendered` / `seen` above), so a view costs
 // 8 bytes read per Gaussian and 64 written per reached one instead of a 64-byte fill of all.
-// Four lanes per record, 16 bytes each.
+// One lane per Gaussian: the hit counts are read coalesced, and only about one record in ten is written.
 __global__ void __launch_bounds__(256) clear_reached_kernel(int P, const float2* gstat, GradRec* acc) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t i = t >> 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    if (gstat[i].y > 0.0f) reinterpret_cast<float4*>(acc + i)[t & 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gstat[i].y > 0.0f) {
+        float4* r = reinterpret_cast<float4*>(acc + i);
+        r[0] = r[1] = r[2] = r[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 hipError_t launch_clear_reached(int P, const GeomBuf& g, GradRec* acc, hipStream_t st) {
-    const int64_t threads = (int64_t)P * 4;
-    hipLaunchKernelGGL(clear_reached_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, P, g.gstat, acc);
+    hipLaunchKernelGGL(clear_reached_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, g.gstat, acc);
     return hipGetLastError();
 }
 
