@@ -159,3 +159,15 @@ def test_tile_grid_too_large_for_the_rectangle_count_path(oracle):
     rs, ten = scene_to_torch(sc, antialiasing=True)
     f, out = _compare(oracle, sc, rs, ten, True, (0.0, 0.0, 0.0))
     assert f.R > 100000
+
+
+@pytest.mark.parametrize("W,H", [(400, 300), (800, 600), (2560, 1440), (3840, 2208)])
+def test_every_digit_split_of_the_fused_emission(oracle, W, H):
+    """Tile ids of 9, 11, 14 and 16 bits: the emission partitions on 4, 5, 7 and 8 high bits and the
+    segmented pass orders 5, 6, 7 and 8 low bits (13 and 15 bits are the 1080p and 4K cases of the
+    full-size tests).  Keys, lists and ranges bit for bit as always."""
+    sc = synth.tiny_scene(P=3000, width=W, height=H, seed=81, scale=0.12)
+    rs, ten = scene_to_torch(sc, antialiasing=False)
+    f, out = _compare(oracle, sc, rs, ten, False, (0.0, 0.0, 0.0), backward=False)
+    ntiles = ((W + 15) // 16) * ((H + 15) // 16)
+    assert f.R > 4 * 4096 and (f.ranges[:, 1] > f.ranges[:, 0]).sum() > ntiles // 4
