@@ -171,3 +171,12 @@ def test_every_digit_split_of_the_fused_emission(oracle, W, H):
     f, out = _compare(oracle, sc, rs, ten, False, (0.0, 0.0, 0.0), backward=False)
     ntiles = ((W + 15) // 16) * ((H + 15) // 16)
     assert f.R > 4 * 4096 and (f.ranges[:, 1] > f.ranges[:, 0]).sum() > ntiles // 4
+
+
+def test_many_one_tile_gaussians_per_emission_chunk(oracle):
+    """Splats of a pixel or two: fewer than two tiles per Gaussian, so one emission chunk of 4096
+    instances takes its Gaussians from ten and more blocks of 256 (a chunk usually spans two or three)."""
+    sc = synth.tiny_scene(P=60000, width=800, height=600, seed=83, scale=0.002)
+    rs, ten = scene_to_torch(sc, antialiasing=False)
+    f, out = _compare(oracle, sc, rs, ten, False, (0.0, 0.0, 0.0))
+    assert f.R < 2 * (f.radii > 0).sum()
