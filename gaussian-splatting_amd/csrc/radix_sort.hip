@@ -394,9 +394,13 @@ template <int HB>
 __global__ void __launch_bounds__(EP_THREADS) emit_partition_kernel(const EmitPartArgs a) {
     constexpr int NB = 1 << HB;  // segments = values of the high digit
     constexpr int NW = EP_THREADS / 64;
-    __shared__ uint32_t s_off[EP_MAX_BLOCKS * 256 + 1];
-    __shared__ uint32_t s_keys[EP_CHUNK];
-    __shared__ uint32_t s_vals[EP_CHUNK];
+    // The running offsets are needed until the keys exist, the staging area from then on: one piece of LDS
+    // (barriers lie between the last read of the one and the first write of the other).
+    __shared__ uint32_t s_stage[2 * EP_CHUNK];
+    static_assert(EP_MAX_BLOCKS * 256 + 1 <= 2 * EP_CHUNK, "the offsets must fit the staging area");
+    uint32_t* const s_off = s_stage;
+    uint32_t* const s_keys = s_stage;
+    uint32_t* const s_vals = s_stage + EP_CHUNK;
     __shared__ uint32_t s_whist[NW * NB + NB];  // per-wave counters, then the chunk histogram
     __shared__ uint32_t s_dstart[NB];
     __shared__ uint32_t s_gofs[NB];
