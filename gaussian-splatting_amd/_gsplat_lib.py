@@ -98,6 +98,10 @@ def lib():
     L.gsr_sort_pairs_u64_u32.restype = C.c_int
     L.gsr_sort_pairs_u64_u32.argtypes = [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, C.c_size_t, _vp,
                                          C.POINTER(C.c_int)]
+    L.gsr_sort_noalloc_max_pairs.restype = C.c_int64
+    L.gsr_sort_noalloc_max_pairs.argtypes = []
+    L.gsr_sort_pairs_u64_u32_noalloc.restype = C.c_int
+    L.gsr_sort_pairs_u64_u32_noalloc.argtypes = [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, C.POINTER(C.c_int)]
     L.gsr_layout.restype = C.c_int
     L.gsr_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(GsrLayout)]
     L.gsr_sorted_keys_u64.restype = C.c_int
@@ -141,7 +145,7 @@ def lib():
 EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backward_work_bytes",
             "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_backward_blend",
             "gsr_backward_geometry_batch", "gsr_preprocess_batch", "gsr_mark_visible", "gsr_sort_temp_bytes",
-            "gsr_sort_pairs_u64_u32", "gsr_layout", "gsr_sorted_keys_u64", "gsk_dist2_temp_bytes", "gsk_dist2", "gss_ssim_forward",
+            "gsr_sort_pairs_u64_u32", "gsr_sort_noalloc_max_pairs", "gsr_sort_pairs_u64_u32_noalloc", "gsr_layout", "gsr_sorted_keys_u64", "gsk_dist2_temp_bytes", "gsk_dist2", "gss_ssim_forward",
             "gss_ssim_backward", "gss_loss_partial_floats", "gss_l1_ssim_loss_forward", "gss_l1_ssim_loss_backward",
             "gss_l1_partial_floats", "gss_l1_loss_forward", "gss_l1_loss_backward",
             "gso_adam_update", "gso_densify_stats", "gso_compact_temp_bytes", "gso_compact_map",

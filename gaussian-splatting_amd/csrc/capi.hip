@@ -321,6 +321,20 @@ int gsr_sort_pairs_u64_u32(uint64_t* keys0, uint32_t* vals0, uint64_t* keys1, ui
     return hip_status(launch_radix_sort(k, v, n, 0, end_bit, temp, (hipStream_t)stream, result_buffer));
 }
 
+int64_t gsr_sort_noalloc_max_pairs(void) { return sort_static_max_pairs(); }
+
+int gsr_sort_pairs_u64_u32_noalloc(uint64_t* keys0, uint32_t* vals0, uint64_t* keys1, uint32_t* vals1, int64_t n,
+                                   int end_bit, void* stream, int* result_buffer) {
+    if (n < 0 || end_bit < 0 || end_bit > 64 || !result_buffer) return GSR_ERR_ARG;
+    *result_buffer = 0;
+    if (n == 0 || end_bit == 0) return GSR_OK;
+    if (n > sort_static_max_pairs()) return GSR_ERR_LIMIT;
+    if (!keys0 || !vals0 || !keys1 || !vals1) return GSR_ERR_ARG;
+    uint64_t* k[2] = {keys0, keys1};
+    uint32_t* v[2] = {vals0, vals1};
+    return hip_status(launch_radix_sort_static(k, v, n, 0, end_bit, (hipStream_t)stream, result_buffer));
+}
+
 int gsr_layout(int P, int W, int H, int64_t R, GsrLayout* out) {
     if (!out || P < 0 || W <= 0 || H <= 0 || R < 0) return GSR_ERR_ARG;
     char* const z = (char*)4096;  // fake non-null base to turn pointers into offsets
@@ -488,6 +502,7 @@ const char* gsr_status_string(int status) {
         case GSR_ERR_BUFFER: return "caller buffer too small";
         case GSR_ERR_HIP: return "HIP runtime error";
         case GSR_ERR_SORT: return "radix sort look-back did not complete";
+        case GSR_ERR_LIMIT: return "input larger than the fixed scratch of the entry point that does not allocate";
         default: return "unknown status";
     }
 }

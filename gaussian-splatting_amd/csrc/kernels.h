@@ -86,6 +86,11 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* view, u
 // Returns the index (0/1) of the buffer pair that holds the sorted result.
 hipError_t launch_radix_sort(uint64_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit, void* temp,
                              hipStream_t st, int* result_buffer);
+// The same sort with its temp area in a device array of the library (no caller buffer, no allocation);
+// n is limited to sort_static_max_pairs(); calls that overlap on one GPU race.
+int64_t sort_static_max_pairs();
+hipError_t launch_radix_sort_static(uint64_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit,
+                                    hipStream_t st, int* result_buffer);
 // Zeroes the sort's status area and returns where its digit histograms go (for a caller that fills them itself).
 uint32_t* sort_prepare(void* temp, int64_t n, int passes, hipStream_t st, hipError_t* e);
 // Tile ranges and the instance sort's digit histograms from the tile rectangles (image sizes whose

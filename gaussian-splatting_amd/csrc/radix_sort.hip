@@ -10,6 +10,8 @@
 //
 // Traffic per pass: key + 4 B read and written per pair, plus 1 KiB of status
 // words per 4096-pair tile.
+#include <mutex>
+
 #include "kernels.h"
 
 namespace gs {
@@ -768,6 +770,58 @@ hipError_t launch_radix_sort(uint64_t* keys[2], uint32_t* vals[2], int64_t n, in
 hipError_t launch_radix_sort_u32(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit,
                                  void* temp, hipStream_t st, int* result_buffer, bool hist_ready) {
     return radix_sort_impl<uint32_t>(keys, vals, n, begin_bit, end_bit, temp, st, result_buffer, hist_ready);
+}
+
+// ------------------------------------------------------------------ sort without a caller-provided temp area
+// For callers that cannot allocate device memory (HIP graph capture, serving loops): the sort's temp
+// area (digit histograms, tickets, error word, look-back status words) lives in a file-scope device
+// array instead of a buffer the caller brings.  Each GPU holds its own copy of the array at its own
+// address; the address is looked up once per device and kept.  All calls on one GPU share that array:
+// calls that overlap on one GPU (two streams, two threads) race.
+constexpr int64_t SORT_STATIC_MAX_PAIRS = 1ll << 21;
+// header (8 KiB of histograms + ticket and error lines) + 8 passes x 512 tiles x 256 status words
+constexpr size_t SORT_STATIC_BYTES = 8192 + 256 + 256 + (size_t)SORT_MAX_PASSES * (SORT_STATIC_MAX_PAIRS / SORT_TILE) * 256 * 4;
+static __device__ __align__(256) unsigned char scratch[SORT_STATIC_BYTES];
+
+namespace {
+constexpr int STATIC_MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[STATIC_MAX_DEVICES] = {};
+
+// Device address of `scratch` on the current device (hipGetSymbolAddress once per device).
+hipError_t static_scratch(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= STATIC_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return hipSuccess;
+}
+}  // namespace
+
+int64_t sort_static_max_pairs() { return SORT_STATIC_MAX_PAIRS; }
+
+hipError_t launch_radix_sort_static(uint64_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit,
+                                    hipStream_t st, int* result_buffer) {
+    *result_buffer = 0;
+    if (n <= 0 || end_bit <= begin_bit) return hipSuccess;
+    if (n > SORT_STATIC_MAX_PAIRS ||
+        sort_temp_view(nullptr, (size_t)n, sort_passes_for(begin_bit, end_bit)).bytes > SORT_STATIC_BYTES)
+        return hipErrorInvalidValue;
+    void* temp = nullptr;
+    hipError_t e = static_scratch(&temp);
+    if (e != hipSuccess) return e;
+    // radix_sort_impl zeroes the histograms, tickets, error word and status words it is going to use
+    // (hipMemsetAsync on `temp`), so what the previous call left there does not matter
+    return radix_sort_impl<uint64_t>(keys, vals, n, begin_bit, end_bit, temp, st, result_buffer, false);
 }
 
 }  // namespace gs

@@ -45,7 +45,8 @@ typedef enum {
     GSR_ERR_OVERFLOW = -3,   /* number of (Gaussian, tile) instances >= 2^30 */
     GSR_ERR_BUFFER = -4,     /* a caller buffer is smaller than the matching *_bytes query */
     GSR_ERR_HIP = -5,        /* a HIP runtime call failed */
-    GSR_ERR_SORT = -6        /* radix sort look-back did not complete */
+    GSR_ERR_SORT = -6,       /* radix sort look-back did not complete */
+    GSR_ERR_LIMIT = -7       /* input larger than the fixed scratch of gsr_sort_pairs_u64_u32_noalloc */
 } GsrStatus;
 
 /* Inputs of one view.  Nullable pointers select the options exactly as the
@@ -242,6 +243,18 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 size_t gsr_sort_temp_bytes(int64_t n);
 int gsr_sort_pairs_u64_u32(uint64_t* keys0, uint32_t* vals0, uint64_t* keys1, uint32_t* vals1, int64_t n, int end_bit,
                            void* temp, size_t temp_bytes, void* stream, int* result_buffer);
+
+/* The same sort for callers that cannot allocate device memory or bring a temp buffer (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  The sort's temp area (digit histograms, tickets, look-back status words) is a device
+ * array inside the library, 4 MiB per GPU that the library runs on, held until the process ends;
+ * the call allocates and frees nothing.  n is limited to gsr_sort_noalloc_max_pairs() (2^21 pairs);
+ * more returns GSR_ERR_LIMIT.  Every call on a GPU uses that GPU's one array: calls that overlap on
+ * one GPU (two streams, two threads) race; calls on one stream, or otherwise ordered, are fine.
+ * Results are bit-identical to gsr_sort_pairs_u64_u32. */
+int64_t gsr_sort_noalloc_max_pairs(void);
+int gsr_sort_pairs_u64_u32_noalloc(uint64_t* keys0, uint32_t* vals0, uint64_t* keys1, uint32_t* vals1, int64_t n,
+                                   int end_bit, void* stream, int* result_buffer);
 
 /* Debug / test access: byte offsets of the arrays inside the scratch buffers. */
 typedef struct {
