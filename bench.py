@@ -224,6 +224,44 @@ def load_pmc_traffic(P, W, H):
         return {}
 
 
+def launch_ranks(n):
+    """Start `n` copies of this command as ranks 0..n-1 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, rendezvous on 127.0.0.1), wait for them, return the worst exit code.  If a rank fails the
+    others are ended (by their PIDs).  With fewer GPUs than ranks (a rehearsal on a smaller box) the ranks
+    share the devices and exchange through gloo, because RCCL refuses two ranks on one device."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    ndev = torch.cuda.device_count()
+    if ndev < n and "GSPLAT_BENCH_BACKEND" not in env:
+        log(f"launcher: {ndev} GPU(s) for {n} ranks: the ranks share devices and exchange through gloo (rehearsal)")
+        env["GSPLAT_BENCH_BACKEND"] = "gloo"
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r))))
+    worst = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            try:
+                rc = p.wait(timeout=1.0)
+            except subprocess.TimeoutExpired:
+                continue
+            alive.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                log(f"launcher: a rank exited with code {rc}; ending the others")
+                for q in alive:
+                    q.terminate()
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,11 +284,19 @@ def main():
                          "instead of fused_ssim.l1_ssim_loss (the reference-signature runs always do)")
     ap.add_argument("--no-defer", action="store_true",
                     help="run the per-Gaussian backward after every view instead of once per step for all its views")
+    ap.add_argument("--reduce-chunks", type=int, default=6,
+                    help="n_gpus > 1: ranges of Gaussians the per-Gaussian backward runs over, the all-reduce of each "
+                         "range's gradient rows starting as soon as its launch is enqueued (1 = one all-reduce after it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-view / reference-API / FPS measurements")
     ap.add_argument("--fwd-only", action="store_true", help="time rendering only (render FPS)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started plainly (`python bench.py --gpus N`): become the launcher of N ranks, one per GPU.  Nothing in
+        # this process has touched the GPU yet (device_count() does not initialise it); the ranks are child
+        # processes and this one only waits for them and passes rank 0's JSON line through.
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -305,9 +351,14 @@ def main():
 
     host_wait = [0.0]
 
+    reducer = gsdp.GradReducer()
+    grad_tensors = sink.tensors() if use_params else None
+
     def step(k=None, timer=None, overlap=True):
-        # the views are dealt to the current stream and the side streams in turn
-        side = ([torch.cuda.current_stream()] + side_streams) if (overlap and side_streams) else []
+        # the views are dealt to the current stream and the side streams in turn (only when the per-Gaussian
+        # backward is deferred to the flush: otherwise every view's backward writes the shared gradient buffers)
+        side = ([torch.cuda.current_stream()] + side_streams) if (overlap and side_streams and
+                                                                  (sink is None or sink.defer or args.fwd_only)) else []
         if use_params:
             sink.begin_step()
         else:
@@ -336,15 +387,26 @@ def main():
         if len(side) > 1:
             for st in side[1:]:
                 torch.cuda.current_stream().wait_stream(st)
-        if use_params and not args.fwd_only:
-            sink.flush()   # deferred mode: the per-Gaussian backward of all V views, once
-        if world > 1 and not args.fwd_only:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            gsdp.GradReducer().start([p.grad for p in leaves]).wait()
-            e1.record()
-            if k is not None:
-                reducer_ms.append((e0, e1))
+        if args.fwd_only:
+            return out
+        if world == 1:
+            if use_params:
+                sink.flush()   # deferred mode: the per-Gaussian backward of all V views, once
+            return out
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        if use_params:
+            # the per-Gaussian backward range by range; each range's rows go to RCCL (its own stream) as soon
+            # as the launch is enqueued and are exchanged while the later ranges are computed
+            sink.flush(chunks=args.reduce_chunks,
+                       on_chunk=lambda first, count: reducer.start_rows(grad_tensors, first, count))
+        else:
+            reducer.start([p.grad for p in leaves])
+        e1.record()       # the compute stream's own work of the step ends here
+        reducer.wait()    # ... and from here it waits for the exchange
+        e2.record()
+        if k is not None:
+            reducer_ms.append((e0, e1, e2))
         return out
 
     def sync():
@@ -377,6 +439,20 @@ def main():
         tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+
+    # one all-reduce of the whole gradient buffer on its own (every rank takes part)
+    allreduce_alone_ms = None
+    if world > 1 and not args.fwd_only:
+        buf = sink.flat if use_params else torch.zeros(sum(p.numel() for p in leaves), device=dev)
+        ts = []
+        for _ in range(4):
+            buf.zero_()
+            sync()
+            t1 = time.perf_counter()
+            gsdp.GradReducer().start([buf]).wait()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t1) * 1e3)
+        allreduce_alone_ms = float(np.mean(ts[1:]))
 
     deferred = use_params and sink.defer and not args.fwd_only
 
@@ -600,10 +676,17 @@ def main():
             res["one_stream_it_s"] = one_stream_it_s
         res.update(extras)
         if world > 1 and reducer_ms:
-            ms = float(np.mean([a.elapsed_time(b) for a, b in reducer_ms]))
             nbytes = float(sum(p.grad.numel() * 4 for p in leaves))
-            res["allreduce"] = {"ms": ms, "bytes": nbytes,
-                                "bus_GBps": 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9}
+            res["allreduce"] = {
+                "bytes": nbytes, "chunks": args.reduce_chunks if use_params else 1,
+                # per step on the compute stream: the per-Gaussian backward (chunked, exchange running beside it) ...
+                "flush_ms": float(np.mean([a.elapsed_time(b) for a, b, _ in reducer_ms])),
+                # ... and what is left of the exchange after it, which nothing overlaps
+                "exposed_ms": float(np.mean([b.elapsed_time(c) for _, b, c in reducer_ms])),
+                # one all-reduce of the whole flat gradient buffer with nothing else running
+                "standalone_ms": allreduce_alone_ms,
+                "bus_GBps": (2.0 * (world - 1) / world * nbytes / (allreduce_alone_ms * 1e-3) / 1e9)
+                            if allreduce_alone_ms else None}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(P, W, H, seed)

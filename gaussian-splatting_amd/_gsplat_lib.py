@@ -91,6 +91,9 @@ def lib():
     L.gsr_backward_geometry_batch.restype = C.c_int
     L.gsr_backward_geometry_batch.argtypes = [C.POINTER(GsrScene), C.c_int, C.POINTER(GsrBackwardView),
                                               C.POINTER(GsrBackwardIO), _vp]
+    L.gsr_backward_geometry_batch_range.restype = C.c_int
+    L.gsr_backward_geometry_batch_range.argtypes = [C.POINTER(GsrScene), C.c_int, C.POINTER(GsrBackwardView),
+                                                    C.POINTER(GsrBackwardIO), C.c_int, C.c_int, _vp]
     L.gsr_preprocess_batch.restype = C.c_int
     L.gsr_preprocess_batch.argtypes = [C.POINTER(GsrScene), C.c_int, C.POINTER(GsrForwardView), _vp]
     L.gsr_mark_visible.restype = C.c_int
@@ -144,7 +147,7 @@ def lib():
 
 EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backward_work_bytes",
             "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_backward_blend",
-            "gsr_backward_geometry_batch", "gsr_preprocess_batch", "gsr_mark_visible", "gsr_sort_temp_bytes",
+            "gsr_backward_geometry_batch", "gsr_backward_geometry_batch_range", "gsr_preprocess_batch", "gsr_mark_visible", "gsr_sort_temp_bytes",
             "gsr_sort_pairs_u64_u32", "gsr_sort_noalloc_max_pairs", "gsr_sort_pairs_u64_u32_noalloc", "gsr_layout", "gsr_sorted_keys_u64", "gsk_dist2_temp_bytes", "gsk_dist2", "gss_ssim_forward",
             "gss_ssim_backward", "gss_loss_partial_floats", "gss_l1_ssim_loss_forward", "gss_l1_ssim_loss_backward",
             "gss_l1_partial_floats", "gss_l1_loss_forward", "gss_l1_loss_backward",

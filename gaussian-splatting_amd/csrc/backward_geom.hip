@@ -340,7 +340,8 @@ struct BatchView {
 };
 
 struct PreBwdBatchArgs {
-    PreBwdArgs a;  // parameters and outputs; its per-view members are unused
+    PreBwdArgs a;  // parameters and outputs; its per-view members are unused; a.P = end of the Gaussian range
+    int first;     // first Gaussian of the range this launch processes (a multiple of 256)
     int nviews;
     BatchView v[MAX_BATCH_VIEWS];
 };
@@ -352,13 +353,13 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
     constexpr int WAVE_LDS = ShLds<SH_SPLIT16>::bytes_per_wave;
     __shared__ __align__(16) char s_sh[4 * WAVE_LDS];
     const PreBwdArgs& a = b.a;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = b.first + blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wave_g0 = blockIdx.x * 256 + w * 64;
+    const int wave_g0 = b.first + blockIdx.x * 256 + w * 64;
     const int nrows = min(64, a.P - wave_g0);
     if (nrows <= 0) return;
     const bool live = idx < a.P;
-    const size_t i = (size_t)(live ? idx : 0);
+    const size_t i = (size_t)(live ? idx : b.first);
     float* lds = reinterpret_cast<float*>(s_sh + w * WAVE_LDS);
     float* row = lds + lane * REST_ROW_F;
 
@@ -558,18 +559,19 @@ hipError_t launch_means2d_grad(int P, const GeomBuf& g, const GradRec* acc, floa
 }
 
 hipError_t launch_preprocess_bwd_batch(const GsrScene& s, int nviews, const GsrBackwardView* views,
-                                       const GsrBackwardIO& io, hipStream_t st) {
+                                       const GsrBackwardIO& io, int first, int count, hipStream_t st) {
     PreBwdBatchArgs b;
     PreBwdArgs& a = b.a;
     a = PreBwdArgs();
-    a.P = s.P; a.D = s.D; a.M = s.M; a.DIM = s.DIM;
+    b.first = first;
+    a.P = first + count; a.D = s.D; a.M = s.M; a.DIM = s.DIM;
     a.mod = s.scale_modifier; a.raw = s.raw_params;
     a.means3D = s.means3D; a.shs = s.shs; a.shs_rest = s.shs_rest; a.opacities = s.opacities;
     a.scales = s.scales; a.rotations = s.rotations;
     a.dL_dopacity = io.dL_dopacity; a.dL_dmeans3D = io.dL_dmeans3D; a.dL_dsh = io.dL_dsh;
     a.dL_dsh_rest = io.dL_dsh_rest; a.dL_dscales = io.dL_dscales; a.dL_drotations = io.dL_drotations;
     a.dL_dreps = io.dL_dreps;
-    const dim3 grid((s.P + 255) / 256), block(256);
+    const dim3 grid((count + 255) / 256), block(256);
     for (int v0 = 0; v0 < nviews; v0 += MAX_BATCH_VIEWS) {
         b.nviews = nviews - v0 < MAX_BATCH_VIEWS ? nviews - v0 : MAX_BATCH_VIEWS;
         a.accumulate = (io.accumulate || v0 > 0) ? 1 : 0;

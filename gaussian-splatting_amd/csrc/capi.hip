@@ -233,10 +233,17 @@ int gsr_backward_blend(const GsrScene* s, const int* radii, const void* geom_buf
 
 int gsr_backward_geometry_batch(const GsrScene* s, int nviews, const GsrBackwardView* views, const GsrBackwardIO* io,
                                 void* stream) {
+    if (!s) return GSR_ERR_ARG;
+    return gsr_backward_geometry_batch_range(s, nviews, views, io, 0, s->P, stream);
+}
+
+int gsr_backward_geometry_batch_range(const GsrScene* s, int nviews, const GsrBackwardView* views,
+                                      const GsrBackwardIO* io, int first, int count, void* stream) {
     if (!s || !io || nviews < 0 || (nviews > 0 && !views)) return GSR_ERR_ARG;
     if (s->P < 0) return GSR_ERR_ARG;
+    if (first < 0 || count < 0 || (first % PRE_BLOCK) != 0 || (int64_t)first + count > s->P) return GSR_ERR_ARG;
     if (s->DIM != 0 && s->DIM != 4) return GSR_ERR_DIM;
-    if (s->P == 0 || nviews == 0) return GSR_OK;
+    if (s->P == 0 || nviews == 0 || count == 0) return GSR_OK;
     if (!s->means3D || !s->opacities || !s->scales || !s->rotations || !s->shs || !s->shs_rest) return GSR_ERR_ARG;
     if (s->M != 16 || s->D < 0 || s->D > 3 || s->cov3D_precomp || s->colors_precomp) return GSR_ERR_ARG;
     if (!io->dL_dopacity || !io->dL_dmeans3D || !io->dL_dsh || !io->dL_dsh_rest || !io->dL_dscales ||
@@ -252,7 +259,7 @@ int gsr_backward_geometry_batch(const GsrScene* s, int nviews, const GsrBackward
     hipStream_t st = (hipStream_t)stream;
     const bool debug = s->debug != 0;
     mark(s, GSR_EV_BATCH_BEGIN, st);
-    GSR_TRY(launch_preprocess_bwd_batch(*s, nviews, views, *io, st));
+    GSR_TRY(launch_preprocess_bwd_batch(*s, nviews, views, *io, first, count, st));
     mark(s, GSR_EV_BATCH, st);
     return GSR_OK;
 }

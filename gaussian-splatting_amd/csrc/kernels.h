@@ -126,8 +126,9 @@ hipError_t launch_preprocess_bwd(const GsrScene& s, const int* radii, const Geom
 hipError_t launch_means2d_grad(int P, const GeomBuf& g, const GradRec* acc, float* dL_dmeans2D, hipStream_t st);
 // Zeroes the records of the Gaussians that the forward's hit count marks as reached; the rest stay undefined.
 hipError_t launch_clear_reached(int P, const GeomBuf& g, GradRec* acc, hipStream_t st);
+// Gaussians [first, first + count) only; first is a multiple of 256.
 hipError_t launch_preprocess_bwd_batch(const GsrScene& s, int nviews, const GsrBackwardView* views,
-                                       const GsrBackwardIO& io, hipStream_t st);
+                                       const GsrBackwardIO& io, int first, int count, hipStream_t st);
 
 hipError_t launch_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible,
                        int64_t N, int M, const AdamConst& c, hipStream_t st);

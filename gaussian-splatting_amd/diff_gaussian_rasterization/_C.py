@@ -222,17 +222,20 @@ def rasterize_gaussians_backward_blend(background, means3D, radii, opacities, sc
 
 
 def backward_geometry_batch(means3D, opacities, scales, rotations, scale_modifier, sh, sh_rest, degree, reps, raw_params,
-                            views, into, accumulate, debug=False):
+                            views, into, accumulate, debug=False, first=0, count=None):
     """Second half of the backward for a batch of views: `views` is a list of
     dicts (viewmatrix, projmatrix, campos, tanfovx, tanfovy, W, H, antialiasing,
     has_invdepth, radii, geom, work and optionally dL_dmeans2D, a [P,3] tensor
     that receives that view's screen-space gradient); the parameter gradients summed over the
     views are written (or, with `accumulate`, added) into the tensors of `into`
-    (keys means3D, opacity, sh, sh_rest, scales, rotations, reps)."""
+    (keys means3D, opacity, sh, sh_rest, scales, rotations, reps).  `first`, `count`:
+    only the Gaussians [first, first + count) (first a multiple of 256); rows
+    outside the range are not touched."""
     L = lib()
     dev = means3D.device
     P = means3D.size(0)
-    if P == 0 or not views:
+    count = P - first if count is None else count
+    if P == 0 or not views or count == 0:
         return
     keep = []
     with torch.cuda.device(dev):
@@ -260,8 +263,8 @@ def backward_geometry_batch(means3D, opacities, scales, rotations, scale_modifie
                 raise RuntimeError(f"gradient buffer '{key}' must be a contiguous float32 tensor on {dev}")
             setattr(io, field, ptr(t))
         io.accumulate = int(bool(accumulate))
-        check(L.gsr_backward_geometry_batch(C.byref(s), len(views), arr, C.byref(io), stream_of(dev)),
-              "backward_geometry_batch")
+        check(L.gsr_backward_geometry_batch_range(C.byref(s), len(views), arr, C.byref(io), int(first), int(count),
+                                                  stream_of(dev)), "backward_geometry_batch")
 
 
 def preprocess_batch(means3D, opacities, scales, rotations, scale_modifier, sh, sh_rest, degree, reps, raw_params,

@@ -113,10 +113,16 @@ class ParamGradSink:
     Gaussians).  With a sink the backward kernels write (first view of a step)
     or add (later views) straight into persistent buffers, which are installed
     as the parameters' `.grad`.  Call `begin_step()` before the first
-    backward of every optimiser step instead of zeroing the gradients."""
+    backward of every optimiser step instead of zeroing the gradients.
+
+    The buffers are views into ONE flat allocation (`flat`, tensor after tensor,
+    each starting on a 256-byte boundary), so a multi-GPU caller can hand the
+    whole gradient, or the rows of a range of Gaussians, to a collective without
+    gathering them first.  The sink belongs to the parameter objects it was built
+    from: build a new one after densification replaced them."""
 
     NAMES = ("means3D", "sh", "sh_rest", "opacity", "scales", "rotations", "reps")
-    MAX_PENDING = 8
+    ROW_ALIGN = 256   # Gaussian ranges of a chunked flush start at multiples of this
 
     def __init__(self, xyz, features_dc, features_rest, opacity, scaling, rotation, reps=None, defer=False):
         """defer: a view's backward only runs the blend backward (and returns the
@@ -127,21 +133,38 @@ class ParamGradSink:
         `flush()` fills."""
         self.params = dict(means3D=xyz, sh=features_dc, sh_rest=features_rest, opacity=opacity, scales=scaling,
                            rotations=rotation, reps=reps)
-        self.grads = {k: torch.zeros_like(p) for k, p in self.params.items() if p is not None and p.numel() != 0}
-        for k, g in self.grads.items():
-            self.params[k].grad = g
+        live = [(k, p) for k, p in self.params.items() if p is not None and p.numel() != 0]
+        offs, total = {}, 0
+        for k, p in live:
+            offs[k] = total
+            total += (p.numel() + 63) // 64 * 64
+        like = live[0][1]
+        self.flat = torch.zeros((total,), dtype=torch.float32, device=like.device)
+        self.grads = {k: self.flat[offs[k]:offs[k] + p.numel()].view(p.shape) for k, p in live}
+        self.attach()
         self.fresh = True
         self.defer = bool(defer) and "sh_rest" in self.grads and \
             features_dc.size(1) + features_rest.size(1) == 16
         self.pending = []
-        self.pending_cfg = None
         self.prepared = []
+
+    def attach(self):
+        """(Re-)install the buffers as the parameters' `.grad`: `optimizer.zero_grad(set_to_none=True)`
+        (train.py) detaches them, after which an optimizer would see no gradient at all."""
+        for k, g in self.grads.items():
+            p = self.params[k]
+            if p.shape != g.shape or p.device != g.device:
+                raise RuntimeError(f"ParamGradSink: parameter '{k}' changed shape or device since the sink was built "
+                                   "(build a new sink after densification)")
+            if p.grad is not g:
+                p.grad = g
 
     def begin_step(self):
         """The next backward overwrites the buffers, the ones after it accumulate."""
         self.pending = []
         self.prepared = []
         self.fresh = True
+        self.attach()
 
     def prepare_views(self, settings_list):
         """Run the forward preprocess of the views that are going to be rendered from the current
@@ -171,21 +194,66 @@ class ParamGradSink:
                 return d
         return None
 
-    def flush(self):
-        """Run the per-Gaussian backward of the views whose backward was deferred."""
-        if not self.pending:
-            return
-        scale_modifier, degree, debug = self.pending_cfg
+    def num_gaussians(self):
+        return self.params["means3D"].size(0)
+
+    def chunk_bounds(self, chunks):
+        """(first, count) of `chunks` contiguous Gaussian ranges that cover all the Gaussians; every
+        range starts at a multiple of ROW_ALIGN (fewer ranges when there are too few Gaussians)."""
+        P = self.num_gaussians()
+        blocks = (P + self.ROW_ALIGN - 1) // self.ROW_ALIGN
+        chunks = max(1, min(int(chunks), blocks))
+        out = []
+        for c in range(chunks):
+            b0, b1 = blocks * c // chunks, blocks * (c + 1) // chunks
+            first, end = b0 * self.ROW_ALIGN, min(P, b1 * self.ROW_ALIGN)
+            if end > first:
+                out.append((first, end - first))
+        return out or [(0, 0)]
+
+    def _geometry(self, cfg, views, first, count, accumulate):
+        """The per-Gaussian backward of `views` for the Gaussians [first, first + count)."""
+        scale_modifier, degree, debug = cfg
         p = self.params
         empty = torch.Tensor([])
         _C.backward_geometry_batch(p["means3D"], p["opacity"], p["scales"], p["rotations"], scale_modifier, p["sh"],
-                                   p["sh_rest"], degree, empty if p["reps"] is None else p["reps"], True, self.pending,
-                                   self.grads, not self.fresh, debug)
+                                   p["sh_rest"], degree, empty if p["reps"] is None else p["reps"], True, views,
+                                   self.grads, accumulate, debug, first=first, count=count)
+
+    def flush(self, chunks=1, on_chunk=None):
+        """Run the per-Gaussian backward of the views whose backward was deferred.
+
+        chunks / on_chunk: the Gaussians are processed as `chunks` contiguous ranges, one launch
+        after the other on the current stream, and `on_chunk(first, count)` is called right after
+        the launch that completes the gradient rows [first, first + count) of every parameter
+        (they are final once the work enqueued so far has run).  A data-parallel caller starts
+        the exchange of those rows there, so that it overlaps the remaining ranges.  `on_chunk`
+        is also called when nothing was deferred (the gradients are then already complete; if no
+        backward ran at all in this step they are set to zero first)."""
+        groups = []   # views that share scale modifier / SH degree go through one launch
+        for v in self.pending:
+            for cfg, lst in groups:
+                if cfg == v["cfg"]:
+                    lst.append(v)
+                    break
+            else:
+                groups.append((v["cfg"], [v]))
+        if not groups and on_chunk is not None and self.fresh:
+            self.flat.zero_()
+            self.fresh = False
+        for first, count in self.chunk_bounds(chunks if (groups or on_chunk is not None) else 1):
+            accumulate = not self.fresh
+            for cfg, views in groups:
+                self._geometry(cfg, views, first, count, accumulate)
+                accumulate = True
+            if on_chunk is not None:
+                on_chunk(first, count)
         for v in self.pending:   # the screen-space gradients the batch kernel wrote, one tensor per view
             m2 = v["means2D"]
             m2.grad = v["dL_dmeans2D"] if m2.grad is None else m2.grad + v["dL_dmeans2D"]
+        if groups:
+            self.fresh = False
         self.pending = []
-        self.fresh = False
 
     def tensors(self):
         return list(self.grads.values())
@@ -229,17 +297,15 @@ class _RasterizeGaussiansParams(torch.autograd.Function):
         sink = ctx.sink
         empty = torch.Tensor([])
         if sink is not None and sink.defer:
-            cfg = (rs.scale_modifier, rs.sh_degree, rs.debug)
-            if sink.pending and (sink.pending_cfg != cfg or len(sink.pending) >= sink.MAX_PENDING):
-                sink.flush()
             g_means2D, work = _C.rasterize_gaussians_backward_blend(
                 rs.bg, xyz, radii, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix, rs.projmatrix,
                 rs.tanfovx, rs.tanfovy, grad_out_color, grad_out_depth, grad_out_reps, features_dc, rs.sh_degree,
                 rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.antialiasing, rs.debug, reps,
                 features_rest, True, want_means2D=False)
-            sink.pending_cfg = cfg
+            # nothing per Gaussian runs here (this may be a side stream with other views' kernels in flight):
+            # flush() processes every pending view, however many, in launches of up to eight views
             sink.pending.append(dict(
-                viewmatrix=rs.viewmatrix, projmatrix=rs.projmatrix, campos=rs.campos, tanfovx=rs.tanfovx,
+                cfg=(float(rs.scale_modifier), int(rs.sh_degree), bool(rs.debug)), viewmatrix=rs.viewmatrix, projmatrix=rs.projmatrix, campos=rs.campos, tanfovx=rs.tanfovx,
                 tanfovy=rs.tanfovy, W=rs.image_width, H=rs.image_height, antialiasing=rs.antialiasing,
                 has_invdepth=grad_out_depth is not None and grad_out_depth.numel() != 0, radii=radii,
                 geom=geomBuffer, work=work, dL_dmeans2D=g_means2D, means2D=ctx.means2D))

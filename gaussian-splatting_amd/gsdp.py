@@ -4,9 +4,10 @@ The reference trains one view per iteration on one GPU (train.py:172-188) and
 has no distributed mode.  Views are independent given the parameters, so a
 multi-view batch shards by view with no exchange inside the rasterizer: every
 rank holds a full replica of the Gaussians, renders its slice of the batch and
-accumulates gradients locally; one sum all-reduce per parameter tensor (63
-floats per Gaussian with the fork's 4 `reps` channels) then makes every replica
-see the gradient of the whole batch.  `torch.distributed` backend "nccl" is
+accumulates gradients locally; a sum all-reduce of the parameter gradients (63
+floats per Gaussian with the fork's 4 `reps` channels), issued range by range
+of Gaussians while the per-Gaussian backward of the later ranges still runs,
+then makes every replica see the gradient of the whole batch.  `torch.distributed` backend "nccl" is
 RCCL on ROCm (xGMI between the GPUs of a node); "gloo" runs the same code on
 CPU tensors for tests.
 
@@ -26,36 +27,66 @@ def shard_views(n_views, rank, world_size):
 
 
 class GradReducer:
-    """Sums gradients over ranks with one asynchronous all-reduce per tensor,
-    largest first, on the process group's communication stream, so the
-    collectives of the big SH tensor overlap the launches of the small ones
-    and whatever the caller still runs before `wait()`."""
+    """Sums gradients over ranks with asynchronous all-reduces on the process
+    group's communication stream (RCCL: the collective waits for what the
+    current stream has enqueued when it is started, and runs beside what the
+    caller enqueues afterwards).
+
+    `start(tensors)` reduces whole tensors, one collective each, largest first.
+    `start_rows(tensors, first, count)` reduces rows [first, first + count) of
+    every tensor as ONE coalesced collective: with `ParamGradSink.flush(chunks,
+    on_chunk=...)` the rows of a range of Gaussians go out as soon as the launch
+    that completes them is enqueued, and their exchange overlaps the per-Gaussian
+    backward of the remaining ranges.  `wait()` makes the current stream (gloo:
+    the host) wait for everything started."""
 
     def __init__(self, group=None, average=False):
         self.group = group
         self.average = average
         self.pending = []
 
+    def _active(self):
+        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _staged(self, t):
+        """gloo rehearsal of the multi-rank path on GPU tensors: through host memory, synchronously."""
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        t.copy_(h)
+
     def start(self, tensors):
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not self._active():
             return self
         staged = dist.get_backend(self.group) == "gloo"
         for t in sorted((t for t in tensors if t is not None), key=lambda t: -t.numel()):
             if staged and t.is_cuda:
-                # gloo rehearsal of the multi-rank path on GPU tensors: through host memory, synchronously
-                h = t.cpu()
-                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
-                t.copy_(h)
+                self._staged(t)
                 continue
-            self.pending.append((t, dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+            self.pending.append(([t], dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+        return self
+
+    def start_rows(self, tensors, first, count):
+        if not self._active() or count <= 0:
+            return self
+        rows = [t[first:first + count] for t in tensors if t is not None and t.numel() != 0]
+        if dist.get_backend(self.group) == "gloo" and any(t.is_cuda for t in rows):
+            for t in rows:
+                self._staged(t)
+            return self
+        # one coalesced collective for the seven row blocks (a single grouped launch with RCCL)
+        with dist._coalescing_manager(group=self.group, async_ops=True) as cm:
+            for t in rows:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self.pending.append((rows, cm))
         return self
 
     def wait(self):
         ws = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        for t, work in self.pending:
+        for ts, work in self.pending:
             work.wait()
             if self.average:
-                t.div_(ws)
+                for t in ts:
+                    t.div_(ws)
         self.pending = []
 
 
@@ -70,7 +101,7 @@ def reduce_densify_stats(xyz_gradient_accum, denom, max_radii2D, group=None):
         w.wait()
 
 
-def run_views(sink, settings_list, loss_of_view, streams=()):
+def run_views(sink, settings_list, loss_of_view, streams=(), reducer=None, chunks=6):
     """The local views of one step through a `ParamGradSink` (raw-parameter rasterizer path):
     `begin_step`, the forward preprocess of all the views in one pass, `loss_of_view(i, settings)`
     (render view i with `forward_params(..., grad_sink=sink)` and return its scalar loss) and
@@ -80,11 +111,17 @@ def run_views(sink, settings_list, loss_of_view, streams=()):
     kernels of a view leave much of the GPU idle (sort passes that wait on their look-back, the
     ramp-down of the blend kernels), so two or three views in flight finish sooner than one after
     the other.  Gradients are the same sums either way (float atomics: not bit for bit).
-    Returns the detached losses."""
+    The side streams are only used with a deferring sink: without deferral every view's backward
+    writes the shared gradient buffers, which is only ordered on one stream.
+
+    reducer: a `GradReducer`; the flush then runs over `chunks` ranges of Gaussians and the
+    all-reduce of each range's gradient rows starts as soon as its launch is enqueued; the call
+    returns after `reducer.wait()`.  Returns the detached losses."""
     sink.begin_step()
     sink.prepare_views(settings_list)
     main = torch.cuda.current_stream()
-    lanes = [main] + list(streams)
+    streams = list(streams) if sink.defer else []
+    lanes = [main] + streams
     if streams:
         ready = torch.cuda.Event()
         ready.record(main)
@@ -98,7 +135,12 @@ def run_views(sink, settings_list, loss_of_view, streams=()):
         losses.append(loss.detach())
     for st in streams:
         main.wait_stream(st)
-    sink.flush()
+    if reducer is None:
+        sink.flush()
+    else:
+        grads = sink.tensors()
+        sink.flush(chunks=chunks, on_chunk=lambda first, count: reducer.start_rows(grads, first, count))
+        reducer.wait()
     return losses
 
 

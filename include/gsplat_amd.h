@@ -204,6 +204,12 @@ int gsr_backward_blend(const GsrScene* scene, const int* radii, const void* geom
                        const void* image_buffer, int64_t num_rendered, const GsrBackwardIO* io, void* stream);
 int gsr_backward_geometry_batch(const GsrScene* scene, int nviews, const GsrBackwardView* views,
                                 const GsrBackwardIO* io, void* stream);
+/* The same for the Gaussians [first, first + count) only (first a multiple of 256, first + count <= P):
+ * rows of the gradient tensors outside the range are not touched.  A caller that exchanges the
+ * gradients between GPUs runs the ranges one after the other and starts the exchange of a range's
+ * rows as soon as its call is enqueued, so that the exchange overlaps the remaining ranges. */
+int gsr_backward_geometry_batch_range(const GsrScene* scene, int nviews, const GsrBackwardView* views,
+                                      const GsrBackwardIO* io, int first, int count, void* stream);
 
 /* Forward preprocess of a batch of views in one pass over the Gaussians (no counterpart in the
  * reference, which renders one view per iteration; for callers that render several views from the

@@ -442,3 +442,70 @@ def test_run_views_on_side_streams(nstreams):
         ga, gb = A[n].grad.cpu().numpy(), B[n].grad.cpu().numpy()
         assert np.isfinite(gb).all(), n
         assert rel_err(gb, ga) <= REL_TOL, (n, rel_err(gb, ga))
+
+
+@pytest.mark.parametrize("nviews,nstreams,defer,chunks", [(5, 3, False, 1), (11, 3, True, 1), (11, 0, True, 3),
+                                                          (9, 2, True, 8)],
+                         ids=["no_defer_with_streams", "more_than_8_views", "chunked_flush", "chunked_on_streams"])
+def test_run_views_variants(nviews, nstreams, defer, chunks):
+    """gsdp.run_views where it used to be fragile: a sink that does not defer (the side streams must
+    not be used: every view's backward writes the shared buffers), more pending views than one
+    batched launch takes, the flush run over ranges of Gaussians (what a multi-GPU step does, here
+    with a recording stand-in for the reducer), and views whose SH degree differs inside one step."""
+    import gsdp
+    from diff_gaussian_rasterization import GaussianRasterizer, ParamGradSink
+    W, H = 96, 64
+    sc = synth.tiny_scene(P=700, width=W, height=H, seed=43)
+    raw = _raw_scene(sc, seed=8)
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda:0")
+    names = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation", "reps")
+    vals = (sc["means3D"], raw["features_dc"], raw["features_rest"], raw["opacity"], raw["scaling"], raw["rotation"],
+            sc["reps"])
+    A = {n: t(v).requires_grad_(True) for n, v in zip(names, vals)}
+    B = {n: t(v).requires_grad_(True) for n, v in zip(names, vals)}
+    sink_a = ParamGradSink(*[A[n] for n in names])
+    sink_b = ParamGradSink(*[B[n] for n in names], defer=defer)
+    settings = _arc_settings(nviews, W, H)
+    settings[1] = settings[1]._replace(sh_degree=2)   # a second (scale modifier, degree) group inside the step
+    rng = np.random.default_rng(17)
+    ws = [[t(rng.standard_normal(s).astype(np.float32)) for s in ((3, H, W), (1, H, W), (4, H, W))] for _ in range(nviews)]
+
+    def loss_of(P_, sink):
+        def f(i, rs):
+            m2 = torch.zeros_like(P_["xyz"], requires_grad=True)
+            o = GaussianRasterizer(rs).forward_params(
+                P_["xyz"], m2, P_["features_dc"], P_["features_rest"], P_["opacity"], P_["scaling"], P_["rotation"],
+                P_["reps"], grad_sink=sink)
+            return (o[0] * ws[i][0]).sum() + (o[2] * ws[i][1]).sum() + (o[5] * ws[i][2]).sum()
+        return f
+
+    sink_a.begin_step()
+    for i, rs in enumerate(settings):
+        loss_of(A, sink_a)(i, rs).backward()
+
+    class Recorder:   # stands in for gsdp.GradReducer: the ranges it is handed, in order
+        def __init__(self):
+            self.rows = []
+
+        def start_rows(self, tensors, first, count):
+            assert all(x.size(0) == 700 for x in tensors)
+            self.rows.append((first, count))
+
+        def wait(self):
+            pass
+
+    streams = [torch.cuda.Stream() for _ in range(nstreams)]
+    rec = Recorder() if chunks > 1 else None
+    for _ in range(2):
+        for p in B.values():
+            p.grad = None   # optimizer.zero_grad(set_to_none=True): the sink re-attaches its buffers
+        gsdp.run_views(sink_b, settings, loss_of(B, sink_b), streams, reducer=rec, chunks=chunks)
+    torch.cuda.synchronize()
+    if rec is not None:
+        per_step = rec.rows[:len(rec.rows) // 2]
+        assert per_step == [(0, 256), (256, 256), (512, 188)]   # 700 rows are three blocks of 256
+    for n in names:
+        assert B[n].grad is not None, n
+        ga, gb = A[n].grad.cpu().numpy(), B[n].grad.cpu().numpy()
+        assert np.isfinite(gb).all(), n
+        assert rel_err(gb, ga) <= REL_TOL, (n, rel_err(gb, ga))

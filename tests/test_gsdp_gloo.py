@@ -83,3 +83,112 @@ def test_single_process_is_a_no_op_reduce():
     sum(_loss(ref, v) for v in views).backward()
     for a, b in zip(params, ref):
         assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------- ParamGradSink -> GradReducer, chunked
+def _sink_problem():
+    g = torch.Generator().manual_seed(3)
+    P = 1000   # four blocks of 256 rows, the last one partial
+    shapes = dict(xyz=(P, 3), dc=(P, 1, 3), rest=(P, 15, 3), opacity=(P, 1), scaling=(P, 3), rotation=(P, 4), reps=(P, 4))
+    params = {k: torch.randn(*s, generator=g) for k, s in shapes.items()}
+    views = [torch.randn(P, generator=g) for _ in range(5)]
+    return params, views
+
+
+def _view_grad(p, w):
+    """The stand-in for one view's per-Gaussian backward: row i of every gradient is w[i] * sin(parameter row)."""
+    return w.view(-1, *([1] * (p.dim() - 1))) * torch.sin(p)
+
+
+def _make_fake_sink(params):
+    from diff_gaussian_rasterization import ParamGradSink
+
+    class FakeSink(ParamGradSink):
+        """The kernels replaced by CPU arithmetic with the same contract: rows [first, first + count) of every
+        gradient are overwritten or added to, rows outside are not touched."""
+        launches = []
+
+        def _geometry(self, cfg, views, first, count, accumulate):
+            self.launches.append((first, count, len(views), accumulate))
+            for k, g in self.grads.items():
+                rows = sum(_view_grad(self.params[k], v["w"])[first:first + count] for v in views)
+                if accumulate:
+                    g[first:first + count] += rows
+                else:
+                    g[first:first + count] = rows
+
+    leaves = [params[k].clone().requires_grad_(True) for k in ("xyz", "dc", "rest", "opacity", "scaling", "rotation", "reps")]
+    sink = FakeSink(*leaves, defer=True)
+    return sink, leaves
+
+
+def _sink_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gsdp
+    params, views = _sink_problem()
+    sink, leaves = _make_fake_sink(params)
+    assert sink.defer
+    out = {}
+    for name, nviews, chunks in (("five_views_3_chunks", 5, 3), ("one_view_8_chunks", 1, 8), ("five_views_unchunked", 5, 1)):
+        for p in leaves:
+            p.grad = None              # what optimizer.zero_grad(set_to_none=True) does between steps
+        sink.begin_step()
+        sink.flat.fill_(float("nan"))  # stale contents must not survive
+        for vi in gsdp.shard_views(nviews, rank, world):
+            sink.pending.append(dict(cfg=(1.0, 3, False), w=views[vi], means2D=torch.zeros(3, requires_grad=True),
+                                     dL_dmeans2D=torch.ones(3)))
+        red = gsdp.GradReducer()
+        seen = []
+        grads = sink.tensors()
+
+        def on_chunk(first, count):
+            seen.append((first, count))
+            red.start_rows(grads, first, count)
+
+        sink.flush(chunks=chunks, on_chunk=on_chunk)
+        red.wait()
+        assert all(p.grad is sink.grads[k] for p, k in zip(leaves, sink.NAMES)), "gradients are not the sink's buffers"
+        assert all(f % 256 == 0 for f, _ in seen) and sum(c for _, c in seen) == 1000
+        out[name] = dict(grads=[p.grad.clone() for p in leaves], chunks=seen)
+    torch.save(out, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_param_grad_sink_chunked_reduce_world2(tmp_path):
+    world = 2
+    mp.start_processes(_sink_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True,
+                       start_method="spawn")
+    params, views = _sink_problem()
+    order = ("xyz", "dc", "rest", "opacity", "scaling", "rotation", "reps")
+    for r in range(world):
+        got = torch.load(os.path.join(tmp_path, f"s{r}.pt"), weights_only=True)
+        for name, nviews in (("five_views_3_chunks", 5), ("one_view_8_chunks", 1), ("five_views_unchunked", 5)):
+            for g, k in zip(got[name]["grads"], order):
+                ref = sum(_view_grad(params[k], views[v]) for v in range(nviews))
+                assert torch.allclose(g, ref, rtol=1e-5, atol=1e-6), (name, k, r)
+        assert len(got["five_views_3_chunks"]["chunks"]) == 3
+        assert len(got["one_view_8_chunks"]["chunks"]) == 4     # 1000 rows are four blocks of 256
+        # chunked and unchunked reduce give the same sums (same per-row addition order on both ranks)
+        for a, b in zip(got["five_views_3_chunks"]["grads"], got["five_views_unchunked"]["grads"]):
+            assert torch.equal(a, b)
+
+
+def test_param_grad_sink_flat_buffer_and_reattach():
+    params, _ = _sink_problem()
+    sink, leaves = _make_fake_sink(params)
+    # every gradient is a contiguous view into the one flat buffer, in NAMES order
+    base = sink.flat.data_ptr()
+    last = -1
+    for k in sink.NAMES:
+        g = sink.grads[k]
+        assert g.is_contiguous() and g.shape == sink.params[k].shape
+        off = g.data_ptr() - base
+        assert off > last and off % 256 == 0 and off + g.numel() * 4 <= sink.flat.numel() * 4
+        last = off
+    leaves[0].grad = None
+    sink.begin_step()
+    assert leaves[0].grad is sink.grads["means3D"]
+    sink.params["means3D"] = torch.zeros(7, 3)
+    with pytest.raises(RuntimeError):
+        sink.begin_step()
