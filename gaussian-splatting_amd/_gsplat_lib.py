@@ -29,7 +29,7 @@ class GsrForwardOut(C.Structure):
     _fields_ = [(n, _vp) for n in ("out_color", "out_invdepth", "radii", "accum_alpha", "gauss_sum", "gauss_count",
                                    "last_contr_gauss", "out_depths", "out_reps")] + \
                [("geom_buffer", _vp), ("geom_bytes", C.c_size_t), ("image_buffer", _vp), ("image_bytes", C.c_size_t),
-                ("num_visible", C.c_int64), ("preprocessed", C.c_int)]
+                ("num_visible", C.c_int64), ("preprocessed", C.c_int), ("sort_error_host", _vp)]
 
 
 class GsrBackwardIO(C.Structure):
@@ -80,6 +80,10 @@ def lib():
     L.gsr_backward_work_bytes.argtypes = [C.c_int]
     L.gsr_sort_temp_bytes.restype = C.c_size_t
     L.gsr_sort_temp_bytes.argtypes = [C.c_int64]
+    L.gsr_sort_temp_error_offset.restype = C.c_size_t
+    L.gsr_sort_temp_error_offset.argtypes = []
+    L.gsr_test_inject_sort_error.restype = None
+    L.gsr_test_inject_sort_error.argtypes = [C.c_int]
     L.gsr_forward_stage1.restype = C.c_int
     L.gsr_forward_stage1.argtypes = [C.POINTER(GsrScene), C.POINTER(GsrForwardOut), _vp, C.POINTER(C.c_int64)]
     L.gsr_forward_stage2.restype = C.c_int
@@ -147,7 +151,7 @@ def lib():
 
 EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backward_work_bytes",
             "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_backward_blend",
-            "gsr_backward_geometry_batch", "gsr_backward_geometry_batch_range", "gsr_preprocess_batch", "gsr_mark_visible", "gsr_sort_temp_bytes",
+            "gsr_backward_geometry_batch", "gsr_backward_geometry_batch_range", "gsr_preprocess_batch", "gsr_mark_visible", "gsr_sort_temp_bytes", "gsr_sort_temp_error_offset", "gsr_test_inject_sort_error",
             "gsr_sort_pairs_u64_u32", "gsr_sort_noalloc_max_pairs", "gsr_sort_pairs_u64_u32_noalloc", "gsr_layout", "gsr_sorted_keys_u64", "gsk_dist2_temp_bytes", "gsk_dist2", "gss_ssim_forward",
             "gss_ssim_backward", "gss_loss_partial_floats", "gss_l1_ssim_loss_forward", "gss_l1_ssim_loss_backward",
             "gss_l1_partial_floats", "gss_l1_loss_forward", "gss_l1_loss_backward",
@@ -173,6 +177,59 @@ def set_profile_events(arr):
 
 def profile_events():
     return _profile_events
+
+
+class SortErrorWords:
+    """Where the sort's error word of every forward call lands without making the host wait.
+
+    The look-back spins of the radix sort are bounded; a tripped limit leaves an error word on the
+    device and an invalid instance list.  Each `rasterize_gaussians` call hands stage 2 one pinned
+    host word (GsrForwardOut.sort_error_host) and records an event behind it; every later call
+    into the rasterizer looks at the words whose event has completed and raises if one is set, so
+    the failure surfaces at the next call after the GPU got there instead of never."""
+
+    SLOTS = 256
+
+    def __init__(self):
+        self.words = None
+        self.pending = []   # (event, slot)
+        self.free = list(range(self.SLOTS))
+
+    def poll(self, block=False):
+        keep = []
+        bad = False
+        for ev, slot in self.pending:
+            if block:
+                ev.synchronize()
+            if block or ev.query():
+                bad = bad or int(self.words[slot]) != 0
+                self.free.append(slot)
+            else:
+                keep.append((ev, slot))
+        self.pending = keep
+        if bad:
+            raise RuntimeError("rasterize_gaussians: " + lib().gsr_status_string(-6).decode() +
+                               " in an earlier forward call (-6): its instance list and everything rendered from it "
+                               "are invalid")
+
+    def take(self):
+        """Address of a zeroed host word for the next stage-2 call, and its slot."""
+        if self.words is None:
+            self.words = torch.zeros(self.SLOTS, dtype=torch.int32).pin_memory()
+        self.poll()
+        if not self.free:
+            self.poll(block=True)
+        slot = self.free.pop()
+        self.words[slot] = 0
+        return self.words.data_ptr() + 4 * slot, slot
+
+    def submitted(self, slot, device):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self.pending.append((ev, slot))
+
+
+sort_errors = SortErrorWords()
 
 
 def check(rc, what):

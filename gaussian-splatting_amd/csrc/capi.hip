@@ -1,11 +1,15 @@
 // extern "C" entry points of libgsplat_amd.so (declared in include/gsplat_amd.h).
 // Host orchestration only: argument checks, scratch-buffer carving, kernel
 // launches on the caller's stream.  Re-entrant, no globals, no allocation.
+#include <atomic>
+
 #include "kernels.h"
 
 using namespace gs;
 
 namespace {
+
+std::atomic<int> g_inject_sort_error{0};  // test hook only (gsr_test_inject_sort_error)
 
 inline int hip_status(hipError_t e) { return e == hipSuccess ? GSR_OK : GSR_ERR_HIP; }
 
@@ -54,6 +58,11 @@ size_t gsr_geom_bytes(int P) { return geom_buf(nullptr, (size_t)(P > 0 ? P : 0))
 size_t gsr_image_bytes(int W, int H) { return image_view(nullptr, (size_t)W, (size_t)H).bytes; }
 size_t gsr_binning_bytes(int64_t R) { return bin_view(nullptr, (size_t)(R > 0 ? R : 0)).bytes; }
 size_t gsr_backward_work_bytes(int P) { return align_up((size_t)(P > 0 ? P : 1) * sizeof(GradRec), 256); }
+size_t gsr_sort_temp_error_offset(void) {
+    char* const z = (char*)4096;
+    return (size_t)((char*)sort_temp_view(z, 1, 0).err - z);
+}
+void gsr_test_inject_sort_error(int on) { g_inject_sort_error.store(on ? 1 : 0, std::memory_order_relaxed); }
 size_t gsr_sort_temp_bytes(int64_t n) { return sort_temp_view(nullptr, (size_t)(n > 0 ? n : 1), SORT_MAX_PASSES).bytes; }
 
 int gsr_forward_stage1(const GsrScene* s, GsrForwardOut* o, void* stream, int64_t* num_rendered) {
@@ -160,12 +169,22 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
         GSR_TRY(launch_finish_gstat(g, s->P, o->gauss_sum, o->gauss_count, st));
         mark(s, GSR_EV_FINISH, st);
     }
-    if (debug && R > 0) {
-        const SortTemp t = sort_temp_view(bin_view(binning_buffer, (size_t)R).sort_temp, (size_t)R,
-                                          sort_passes_for(0, tile_bits(s->W, s->H)));
-        uint32_t err = 0;
-        if (hipMemcpy(&err, t.err, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess) return GSR_ERR_HIP;
-        if (err) return GSR_ERR_SORT;
+    // The sorts' look-back spins are bounded; a tripped limit sets an error word in the sort's temp area.
+    // With debug the call waits and reports it; otherwise the word goes to the caller's host word in
+    // stream order (no wait here), or stays unread if the caller gave none.
+    if (R > 0 && s->P > 0 && (debug || o->sort_error_host)) {
+        const SortTemp t = sort_temp_view(bin_view(binning_buffer, (size_t)R).sort_temp, 1, 0);
+        if (g_inject_sort_error.load(std::memory_order_relaxed) &&
+            hipMemsetAsync(t.err, 1, 1, st) != hipSuccess)
+            return GSR_ERR_HIP;
+        if (debug) {
+            uint32_t err = 0;
+            if (hipMemcpyAsync(&err, t.err, sizeof(err), hipMemcpyDeviceToHost, st) != hipSuccess) return GSR_ERR_HIP;
+            if (hipStreamSynchronize(st) != hipSuccess) return GSR_ERR_HIP;
+            if (err) return GSR_ERR_SORT;
+        } else if (hipMemcpyAsync(o->sort_error_host, t.err, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) {
+            return GSR_ERR_HIP;
+        }
     }
     return GSR_OK;
 }

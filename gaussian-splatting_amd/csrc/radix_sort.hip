@@ -417,7 +417,6 @@ __global__ void __launch_bounds__(EP_THREADS) emit_partition_kernel(const EmitPa
     const uint32_t chunk = s_chunk;
     const uint32_t i0 = chunk * EP_CHUNK;             // first instance of the chunk
     const uint32_t chunk_n = min((uint32_t)EP_CHUNK, a.R - i0);
-    const uint32_t i1 = i0 + chunk_n;
     // The chunk's Gaussians: those of the block its first instance falls in up to the block in which
     // the next chunk starts (one more than needed when that one starts exactly at a block boundary;
     // its entries are then never chosen).  Their running instance offsets go to LDS: every thread

@@ -147,9 +147,14 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
             f2 g_rg = {0.f, 0.f}, g_bd = {0.f, 0.f}, g_r01 = {0.f, 0.f}, g_r23 = {0.f, 0.f};
 
             if (lane_in(vm)) {
-                // 1 / (1 - alpha) by v_rcp_f32 (1 ulp): the gradients are sums of atomics anyway, and an
-                // IEEE divide is ten instructions of the ~100 in this body.
-                const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                // 1 / (1 - alpha): v_rcp_f32 plus one Newton step (two fused multiply-adds).  The bare
+                // v_rcp_f32 (1 ulp, not unbiased) is not enough: T is recovered by one such division
+                // per blended Gaussian, its error grows along the list, and in gradients that are small
+                // sums of large terms it showed up as 3e-4 relative against a divide; with the step
+                // the results match an IEEE divide (ten instructions) within the 1e-4 bar element-wise.
+                const float oma = 1.f - alpha;
+                float inv_1ma = __builtin_amdgcn_rcpf(oma);
+                inv_1ma = fmaf(fmaf(-oma, inv_1ma, 1.0f), inv_1ma, inv_1ma);
                 T = T * inv_1ma;
                 const float dchannel_dcolor = alpha * T;
                 const f2 dc2 = {dchannel_dcolor, dchannel_dcolor};

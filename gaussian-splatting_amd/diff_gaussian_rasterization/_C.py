@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from _gsplat_lib import (GsrBackwardIO, GsrBackwardView, GsrForwardOut, GsrForwardView, GsrScene, check, dev_f32, lib,
-                         profile_events, ptr, stream_of)
+                         profile_events, ptr, sort_errors, stream_of)
 
 SUPPORTED_DIMS = (0, 4)
 
@@ -106,8 +106,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             check(L.gsr_forward_stage1(C.byref(s), C.byref(o), st, C.byref(R)), "rasterize_gaussians (stage 1)")
             R = int(R.value)
         binning = torch.empty((L.gsr_binning_bytes(R) if R > 0 else 0,), **u8)
-        check(L.gsr_forward_stage2(C.byref(s), C.byref(o), R, ptr(binning), binning.numel(), st),
-              "rasterize_gaussians (stage 2)")
+        # the sort's error word comes back through a pinned host word, looked at by later calls (no wait here)
+        o.sort_error_host, slot = sort_errors.take()
+        try:
+            check(L.gsr_forward_stage2(C.byref(s), C.byref(o), R, ptr(binning), binning.numel(), st),
+                  "rasterize_gaussians (stage 2)")
+        finally:
+            sort_errors.submitted(slot, dev)
     return (R, out_color, radii, geom, binning, img, out_invdepth, accum_alpha, gauss_sum, gauss_count, last_contr,
             out_depths, out_reps)
 
@@ -126,6 +131,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
     sh_rest, scales, rotations, reps) that the kernels write directly, adding
     to their contents when `accumulate` is set."""
     L = lib()
+    sort_errors.poll()
     dev = means3D.device
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -195,6 +201,7 @@ def rasterize_gaussians_backward_blend(background, means3D, radii, opacities, sc
     (dL_dmeans2D, work); `work` goes to backward_geometry_batch later, which
     can also fill dL_dmeans2D (want_means2D=False leaves it uninitialised here)."""
     L = lib()
+    sort_errors.poll()
     dev = means3D.device
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)

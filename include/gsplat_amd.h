@@ -133,6 +133,11 @@ typedef struct {
                                 < 0 there means "not known" and all P are ordered. */
     int preprocessed;        /* nonzero: geom_buffer, radii and out_depths were filled by gsr_preprocess_batch for
                                 this view; gsr_forward_stage1 then only runs the prefix sums */
+    uint32_t* sort_error_host; /* NULL, or HOST memory (pinned, so that the copy is asynchronous) that receives the
+                                radix sort's error word at the end of gsr_forward_stage2, in stream order: nonzero
+                                once the stream has passed that point = a look-back did not complete and the instance
+                                list is not valid (what GSR_ERR_SORT reports when scene->debug makes the call wait).
+                                The word must stay valid until the stream has passed the call. */
 } GsrForwardOut;
 
 /* Gradients.  Inputs are the three per-pixel gradients; every output is fully
@@ -247,6 +252,9 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  * Both buffer pairs are clobbered; on return *result_buffer (0 or 1) says which
  * pair holds the sorted data. */
 size_t gsr_sort_temp_bytes(int64_t n);
+/* Byte offset, inside `temp`, of the sort's error word (u32): nonzero after the sort has run = a look-back
+ * did not complete within its spin limit and the output is not valid. */
+size_t gsr_sort_temp_error_offset(void);
 int gsr_sort_pairs_u64_u32(uint64_t* keys0, uint32_t* vals0, uint64_t* keys1, uint32_t* vals1, int64_t n, int end_bit,
                            void* temp, size_t temp_bytes, void* stream, int* result_buffer);
 
@@ -346,6 +354,9 @@ size_t gso_compact_temp_bytes(int64_t N);
 int gso_compact_map(int64_t N, const uint8_t* keep, uint32_t* src_of_dst, void* temp, size_t temp_bytes, int64_t* kept,
                     void* stream);
 int gso_gather_rows(const void* src, void* dst, const uint32_t* src_of_dst, int64_t K, int M, void* stream);
+
+/* Test hook: while on, every gsr_forward_stage2 sets its sort's error word as a tripped look-back would. */
+void gsr_test_inject_sort_error(int on);
 
 const char* gsr_status_string(int status);
 

@@ -339,7 +339,7 @@ struct PixBwd {
 
 // part layout per instance: [0..1] mean2D, [2..4] conic x,y,w, [5] opacity, [6..8] colour, [9] invdepth, [10..] reps
 static void render_tile_bwd(const GsoScene& s, const Cam& c, const GsoGeom& g, const GsoBin& b, const GsoImage& im,
-                            const GsoGrads& gr, int tx, int ty, const float* feat, float* part, int stride) {
+                            const GsoGrads& gr, int tx, int ty, const float* feat, double* part, int stride) {
     const int W = s.W, H = s.H, DIM = s.DIM;
     const int tile = ty * c.grid_x + tx;
     const uint32_t r0 = im.ranges[2 * tile], r1 = im.ranges[2 * tile + 1];
@@ -369,7 +369,7 @@ static void render_tile_bwd(const GsoScene& s, const Cam& c, const GsoGeom& g, c
         const V2 xy = {g.means2D[2 * gid], g.means2D[2 * gid + 1]};
         const V4 co = {g.conic_opacity[4 * gid], g.conic_opacity[4 * gid + 1], g.conic_opacity[4 * gid + 2],
                        g.conic_opacity[4 * gid + 3]};
-        float* acc = part + (size_t)i * stride;
+        double* acc = part + (size_t)i * stride;
         for (int t = 0; t < TILE_PIX; ++t) {
             PixBwd& p = st[t];
             if (!p.inside || contributor >= p.last_contributor) continue;
@@ -476,22 +476,33 @@ int gso_backward(const GsoScene* sp, const GsoGeom* g, const GsoBin* b, const Gs
     const float* feat = s.colors_precomp ? s.colors_precomp : g->rgb;
     const int stride = 10 + s.DIM;
     {
-        std::vector<float> part((size_t)std::max<int64_t>(R, 1) * stride, 0.0f);
+        // The reference adds every pair's terms to the per-Gaussian gradients with float atomics, in no
+        // defined order.  The checker takes the order out of the result: each term is formed in float as
+        // the reference forms it, the SUMS are carried in double (per instance, then per Gaussian in list
+        // order) and rounded to float once.  A float implementation is compared with this at 1e-4.
+        std::vector<double> part((size_t)std::max<int64_t>(R, 1) * stride, 0.0);
 #pragma omp parallel for collapse(2) schedule(dynamic)
         for (int ty = 0; ty < c.grid_y; ++ty)
             for (int tx = 0; tx < c.grid_x; ++tx) render_tile_bwd(s, c, *g, *b, *im, *gr, tx, ty, feat, part.data(), stride);
+        std::vector<double> sum((size_t)std::max(s.P, 1) * stride, 0.0);
         for (int64_t i = 0; i < R; ++i) {
             const uint32_t gid = b->point_list[i];
-            const float* a = &part[(size_t)i * stride];
-            gr->dL_dmean2D[3 * gid + 0] += a[0];
-            gr->dL_dmean2D[3 * gid + 1] += a[1];
-            gr->dL_dconic[4 * gid + 0] += a[2];
-            gr->dL_dconic[4 * gid + 1] += a[3];
-            gr->dL_dconic[4 * gid + 3] += a[4];
-            gr->dL_dopacity[gid] += a[5];
-            for (int ch = 0; ch < 3; ++ch) gr->dL_dcolor[3 * gid + ch] += a[6 + ch];
-            if (gr->dL_dinvdepths) gr->dL_dinvdepths[gid] += a[9];
-            for (int ch = 0; ch < s.DIM; ++ch) gr->dL_dreps[(size_t)gid * s.DIM + ch] += a[10 + ch];
+            const double* a = &part[(size_t)i * stride];
+            double* d = &sum[(size_t)gid * stride];
+            for (int k = 0; k < stride; ++k) d[k] += a[k];
+        }
+#pragma omp parallel for schedule(static, 4096)
+        for (int gid = 0; gid < s.P; ++gid) {
+            const double* a = &sum[(size_t)gid * stride];
+            gr->dL_dmean2D[3 * gid + 0] += (float)a[0];
+            gr->dL_dmean2D[3 * gid + 1] += (float)a[1];
+            gr->dL_dconic[4 * gid + 0] += (float)a[2];
+            gr->dL_dconic[4 * gid + 1] += (float)a[3];
+            gr->dL_dconic[4 * gid + 3] += (float)a[4];
+            gr->dL_dopacity[gid] += (float)a[5];
+            for (int ch = 0; ch < 3; ++ch) gr->dL_dcolor[3 * gid + ch] += (float)a[6 + ch];
+            if (gr->dL_dinvdepths) gr->dL_dinvdepths[gid] += (float)a[9];
+            for (int ch = 0; ch < s.DIM; ++ch) gr->dL_dreps[(size_t)gid * s.DIM + ch] += (float)a[10 + ch];
         }
     }
     const float* cov3D = s.cov3D_precomp ? s.cov3D_precomp : g->cov3D;

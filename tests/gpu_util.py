@@ -71,6 +71,21 @@ def read_internals(out, P, W, H):
     return res
 
 
-def rel_err(got, ref):
+def rel_err(got, ref, floor=1e-2):
+    """Element-wise error measure for sums whose order is not defined (float atomics): the largest
+    |got - ref| / (|ref| + floor * max|ref|).  rel_err <= 1e-4 says that EVERY element obeys
+    |got - ref| <= 1e-4 |ref| + 1e-6 max|ref|: an element far below the tensor's maximum cannot be
+    wrong by more than a millionth of that maximum plus 1e-4 of itself."""
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
-    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+    if ref.size == 0:
+        return 0.0
+    top = float(np.abs(ref).max())
+    return float((np.abs(got - ref) / (np.abs(ref) + floor * top + 1e-300)).max())
+
+
+def worst(got, ref, floor=1e-2):
+    """Where rel_err is attained: (flat index, got, ref, max|ref|), for assertion messages."""
+    got, ref = np.asarray(got, np.float64).reshape(-1), np.asarray(ref, np.float64).reshape(-1)
+    top = float(np.abs(ref).max())
+    i = int(np.argmax(np.abs(got - ref) / (np.abs(ref) + floor * top + 1e-300)))
+    return i, float(got[i]), float(ref[i]), top

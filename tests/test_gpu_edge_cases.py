@@ -180,3 +180,42 @@ def test_many_one_tile_gaussians_per_emission_chunk(oracle):
     rs, ten = scene_to_torch(sc, antialiasing=False)
     f, out = _compare(oracle, sc, rs, ten, False, (0.0, 0.0, 0.0))
     assert f.R < 2 * (f.radii > 0).sum()
+
+
+def test_sort_error_word_is_surfaced_without_debug():
+    """A look-back that trips its spin limit leaves an error word on the device.  With debug the forward
+    call waits and fails; without it the call returns (it must not wait), and the next call into the
+    rasterizer after the GPU has passed that point raises.  The error is injected through the test hook."""
+    import synth
+    from _gsplat_lib import lib, sort_errors
+    from gpu_util import run_forward_raw, scene_to_torch
+    L = lib()
+    sc = synth.tiny_scene(P=300, width=64, height=48, seed=3)
+    sort_errors.poll(block=True)
+    try:
+        L.gsr_test_inject_sort_error(1)
+        rs, ten = scene_to_torch(sc, debug=True)
+        with pytest.raises(RuntimeError, match="look-back"):
+            run_forward_raw(rs, ten)
+        sort_errors.poll(block=True)          # the debug call reported it itself: nothing is left pending
+    finally:
+        L.gsr_test_inject_sort_error(0)
+    try:
+        L.gsr_test_inject_sort_error(1)
+        rs, ten = scene_to_torch(sc, debug=False)
+        out = run_forward_raw(rs, ten)        # returns: the host does not wait for the word
+        assert out["num_rendered"] > 0
+    finally:
+        L.gsr_test_inject_sort_error(0)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="look-back"):
+        run_forward_raw(rs, ten)              # the next call finds the word of the one before
+    out = run_forward_raw(rs, ten)            # and the state is clean again
+    torch.cuda.synchronize()
+    sort_errors.poll(block=True)
+
+
+def test_sort_error_offset_is_inside_the_temp_area():
+    from _gsplat_lib import lib
+    L = lib()
+    assert 0 < L.gsr_sort_temp_error_offset() < L.gsr_sort_temp_bytes(1)

@@ -141,7 +141,9 @@ def test_raw_params_forward_backward(oracle, name, make, aa, bg, split):
     for i, key in pairs:
         assert res3[i].data_ptr() == into[key].data_ptr()          # written in place
         want = (res[i].double() + res2[i].double()).cpu().numpy()
-        assert rel_err(into[key].cpu().numpy(), want) <= 1e-6, key
+        # two launches of the backward blend order their float atomics differently: the recomputed second
+        # term differs from res2 by that noise; an accumulation that overwrote or doubled would be off by O(1)
+        assert rel_err(into[key].cpu().numpy(), want) <= 2e-5, key
     # the means2D gradient is per view, never accumulated (equal up to the order of the atomics)
     assert rel_err(res3[0].cpu().numpy(), res2[0].cpu().numpy()) <= 1e-5
 

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import synth
-from gpu_util import read_internals, rel_err, run_forward_raw, scene_to_torch
+from gpu_util import worst, read_internals, rel_err, run_forward_raw, scene_to_torch
 
 pytestmark = pytest.mark.gpu
 
@@ -137,7 +137,7 @@ def test_backward_parity_precomputed(oracle):
     t = lambda a: torch.tensor(a, device="cuda:0")
     got = _grads_gpu(rs, ten, t(gc), t(gd), t(gr), kw_g, out)
     for k in ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dreps"):
-        assert rel_err(got[k], ref[k].reshape(got[k].shape)) <= REL_TOL, k
+        assert rel_err(got[k], ref[k].reshape(got[k].shape)) <= REL_TOL, (k, worst(got[k], ref[k]), got[k].shape)
 
 
 def test_autograd_module_end_to_end(oracle):
