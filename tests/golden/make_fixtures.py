@@ -5,6 +5,8 @@ the reference that run on a CPU in the build container:
     utils/graphics_utils.getWorld2View2 / getProjectionMatrix / focal2fov
     utils/loss_utils.ssim               (conv2d SSIM, value and autograd gradient;
                                          the pin submodules/fused-ssim/tests/test.py:82-91 uses)
+    utils/loss_utils.l1_loss + ssim     (the training loss as train.py:222-230, 248-251 composes it,
+                                         value and autograd gradient through the clamp)
 
 Run once here:  python tests/golden/make_fixtures.py   (needs /root/reference).
 Only the resulting .npz files (inputs + expected outputs) are committed; the
@@ -70,6 +72,28 @@ def main():
         val.backward()
         out.update({f"img1_{i}": a, f"img2_{i}": b, f"ssim_{i}": np.float32(val.item()), f"grad_{i}": ta.grad.numpy()})
     np.savez(os.path.join(OUT, "ssim_ref.npz"), **out)
+    # --- the photometric training loss as train.py:222-230 composes it, and the feature-map L1 of :248-251
+    from utils.loss_utils import l1_loss
+    out = {}
+    lam = 0.2
+    for i, shape in enumerate([(3, 40, 72), (3, 17, 33)]):
+        raw = (rng.random(shape) * 1.4 - 0.2).astype(np.float32)        # an unclamped render: some values outside [0, 1]
+        gt = rng.random(shape).astype(np.float32)
+        t = torch.tensor(raw, requires_grad=True)
+        image = t.clamp(0, 1)                                            # gaussian_renderer/__init__.py:179
+        Ll1 = l1_loss(image, torch.tensor(gt))
+        ssim_value = ssim(image, torch.tensor(gt))
+        loss = (1.0 - lam) * Ll1 + lam * (1.0 - ssim_value)
+        loss.backward()
+        rep = (rng.standard_normal((4,) + shape[1:]) * 3 + 8).astype(np.float32)
+        tr = torch.tensor(rep, requires_grad=True)
+        Ll1rep = l1_loss(tr, torch.full_like(tr, 10.0))
+        Ll1rep.backward()
+        out.update({f"raw_{i}": raw, f"gt_{i}": gt, f"loss_{i}": np.float32(loss.item()), f"l1_{i}": np.float32(Ll1.item()),
+                    f"ssim_{i}": np.float32(ssim_value.item()), f"grad_{i}": t.grad.numpy(), f"rep_{i}": rep,
+                    f"l1rep_{i}": np.float32(Ll1rep.item()), f"gradrep_{i}": tr.grad.numpy()})
+    out["lambda_dssim"] = np.float32(lam)
+    np.savez(os.path.join(OUT, "train_loss_ref.npz"), **out)
     print("wrote fixtures to", OUT)
 
 

@@ -1,6 +1,8 @@
 """GPU parity at the full sizes of the benchmark configurations.
 
-  C2  2.5 M Gaussians, 1920x1080, render only      full comparison with the CPU checker
+  C1  100 k Gaussians, 800x800, fwd + bwd           full comparison with the CPU checker
+  C2  2.5 M Gaussians, 1920x1080, render only      full comparison with the CPU checker; the fork's
+                                                    statistics invariants on the kernel output
   C3  6 M Gaussians, 1297x840, antialiasing,        full comparison, forward and backward,
       forward + fused-ssim + backward               plus the ssim kernels on the rendered image
   C4  6 M Gaussians, 1920x1080, 8 cameras,          the step as bench.py runs it (batched forward preprocess,
@@ -28,12 +30,71 @@ from test_gpu_rasterizer import ABS_TOL, REL_TOL, _check_forward, _grads_gpu
 pytestmark = pytest.mark.gpu
 
 
+def test_c1_ball_100k_800x800_forward_and_backward(oracle):
+    """C1 at its stated size: 100 k Gaussians, 800x800, forward + backward, white background."""
+    sc = synth.ball_scene(100_000, width=800, height=800)
+    f, out, rs, ten, kw_g = _check_forward(oracle, sc, False, (1.0, 1.0, 1.0))
+    H, W = rs.image_height, rs.image_width
+    rng = np.random.default_rng(6)
+    gc = rng.standard_normal((3, H, W)).astype(np.float32)
+    gd = rng.standard_normal((1, H, W)).astype(np.float32)
+    gr = rng.standard_normal((4, H, W)).astype(np.float32)
+    ref = f.backward(gc, gd, gr)
+    t = lambda a: torch.tensor(a, device="cuda:0")
+    got = _grads_gpu(rs, ten, t(gc), t(gd), t(gr), kw_g, out)
+    torch.cuda.synchronize()
+    for k in got:
+        r = ref[k].reshape(got[k].shape)
+        assert np.isfinite(got[k]).all(), k
+        assert rel_err(got[k], r) <= REL_TOL, (k, rel_err(got[k], r))
+
+
 def test_c2_render_2p5M_1080p(oracle):
     sc = synth.street_scene(2_500_000, 1920, 1080, seed=2)
     t0 = time.time()
     f, out, rs, ten, _ = _check_forward(oracle, sc, False, (0.0, 0.0, 0.0))
     print(f"C2: R={f.R}, forward on both sides + compare {time.time() - t0:.1f}s")
     assert f.R > 5_000_000
+
+
+def test_c2_fork_statistics_invariants_on_the_kernel_output():
+    """The fork's extra outputs at C2 size, on what the HIP kernels produce (no checker involved).
+    The fork author's own test (diff_gaussian_rasterization/__init__.py:130-147) compares, for one
+    Gaussian, the mean final transmittance of the pixels it contributed to last with
+    gauss_sum / gauss_count; that equality needs the alternate accumulation the author left
+    commented out in forward.cu:449-451.  Under the accumulation the fork ships (pre-blend T of every
+    tested pair, forward.cu:431-432) what can be proven for EVERY Gaussian g is:
+      * pixels whose last contributor is g are among the pairs counted for g, and their final T is
+        T_before(g) * (1 - alpha) <= T_before(g):  #pixels(last == g) <= gauss_count[g]  and
+        sum of accum_alpha over those pixels <= gauss_sum[g];
+      * T <= 1:  gauss_sum[g] <= gauss_count[g];  one is zero exactly when the other is;
+      * a pixel nothing contributed to has last_contr_gauss == -1 and accum_alpha == 1."""
+    P, W, H = 2_500_000, 1920, 1080
+    sc = synth.street_scene(P, W, H, seed=2)
+    rs, ten = scene_to_torch(sc, antialiasing=False, debug=False)
+    out = run_forward_raw(rs, ten)
+    torch.cuda.synchronize()
+    last = out["last_contr_gauss"].view(-1).long()
+    T = out["accum_alpha"].view(-1)
+    gsum, gcnt = out["gauss_sum"].double(), out["gauss_count"].long()
+    assert int(last.min()) >= -1 and int(last.max()) < P
+    hit = last >= 0
+    pix_per_g = torch.bincount(last[hit], minlength=P)
+    t_per_g = torch.zeros(P, dtype=torch.float64, device=T.device).index_add_(0, last[hit], T[hit].double())
+    assert bool((pix_per_g <= gcnt).all())
+    assert bool((t_per_g <= gsum * (1 + 1e-4) + 1e-6).all())
+    assert bool((gsum <= gcnt.double() * (1 + 1e-6)).all())
+    assert bool(((gcnt == 0) == (gsum == 0)).all())
+    assert bool((gcnt[out["radii"] == 0] == 0).all())
+    n_contrib = torch.tensor(read_internals(out, P, W, H)["n_contrib"].astype(np.int64), device=T.device)
+    assert bool((last[n_contrib == 0] == -1).all()) and bool((T[n_contrib == 0] == 1.0).all())
+    assert bool((last[n_contrib > 0] >= 0).all())
+    # the author's Gaussian of choice, the farthest one: nothing lies behind it, so wherever it blended it is the
+    # last contributor, and the author's two averages are then ordered the way the inequality above says
+    far = int(torch.argmax(torch.where(out["radii"] > 0, out["out_depths"], torch.full_like(out["out_depths"], -1.0))))
+    if int(pix_per_g[far]) > 0:
+        assert float(t_per_g[far] / pix_per_g[far]) <= 1.0
+    assert int(hit.sum()) > W * H // 2 and int((pix_per_g > 0).sum()) > 1_000
 
 
 def test_c3_train_step_6M_1297x840(oracle):

@@ -155,3 +155,28 @@ def test_l1_loss_equals_torch(shape, target):
     assert torch.allclose(a1.grad, a2.grad, rtol=1e-6, atol=0)
     if target == "tensor":
         assert (a1.grad.view(-1)[::7] == 0).all()
+
+
+def test_fused_losses_match_the_reference_composition():
+    """fused_ssim.l1_ssim_loss and fused_ssim.l1_loss against values and autograd gradients of the
+    reference's own utils/loss_utils.l1_loss + ssim composed as train.py:222-230, 248-251 does
+    (tests/golden/train_loss_ref.npz, written by tests/golden/make_fixtures.py from the reference)."""
+    import os
+    import fused_ssim
+    from gpu_util import rel_err
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_loss_ref.npz"))
+    lam = float(fx["lambda_dssim"])
+    for i in range(2):
+        raw = torch.tensor(fx[f"raw_{i}"], device="cuda:0", requires_grad=True)
+        gt = torch.tensor(fx[f"gt_{i}"], device="cuda:0")
+        loss, parts = fused_ssim.l1_ssim_loss(raw, gt, lam, return_parts=True)
+        loss.backward()
+        assert abs(float(loss) - float(fx[f"loss_{i}"])) <= 2e-6
+        assert abs(float(parts[1]) - float(fx[f"l1_{i}"])) <= 2e-6
+        assert abs(float(parts[2]) - float(fx[f"ssim_{i}"])) <= 2e-6
+        assert rel_err(raw.grad.cpu().numpy(), fx[f"grad_{i}"]) <= 1e-4
+        rep = torch.tensor(fx[f"rep_{i}"], device="cuda:0", requires_grad=True)
+        l1 = fused_ssim.l1_loss(rep, 10.0)
+        l1.backward()
+        assert abs(float(l1) - float(fx[f"l1rep_{i}"])) <= 1e-6 * max(1.0, float(fx[f"l1rep_{i}"]))
+        assert np.allclose(rep.grad.cpu().numpy(), fx[f"gradrep_{i}"], rtol=1e-6, atol=0)

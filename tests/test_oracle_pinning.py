@@ -226,3 +226,23 @@ def test_oracle_reproduces_committed_golden(oracle):
         assert np.abs(f.out_color - fx[f"{name}_color"]).max() <= 1e-6
         for k, v in g.items():
             assert np.abs(v - fx[f"{name}_{k}"]).max() <= 1e-5 * max(1.0, np.abs(v).max()), k
+
+
+def test_training_loss_matches_reference_composition(oracle):
+    """train.py:222-230: (1 - l) * l1_loss(c, gt) + l * (1 - ssim(c, gt)) on c = clamp(render, 0, 1), value and
+    gradient from the reference's own l1_loss / ssim through autograd (fixture), against the same loss composed
+    from the checker's ssim and numpy: what smoke() and bench.py's CPU baseline differentiate through."""
+    fx = np.load(os.path.join(GOLD, "train_loss_ref.npz"))
+    lam = float(fx["lambda_dssim"])
+    for i in range(2):
+        raw, gt = fx[f"raw_{i}"], fx[f"gt_{i}"]
+        c = np.clip(raw, 0, 1)[None]
+        m, d1, d2, d3 = oracle.ssim_fwd(c, gt[None])
+        l1 = np.abs(c - gt[None]).mean(dtype=np.float64)
+        loss = (1 - lam) * l1 + lam * (1 - m.mean(dtype=np.float64))
+        assert abs(loss - float(fx[f"loss_{i}"])) <= 2e-6
+        assert abs(l1 - float(fx[f"l1_{i}"])) <= 1e-6 and abs(m.mean(dtype=np.float64) - float(fx[f"ssim_{i}"])) <= 2e-6
+        g = oracle.ssim_bwd(c, gt[None], np.full(c.shape, -lam / c.size, np.float32), d1, d2, d3)[0]
+        g = g + (1 - lam) * np.sign(c[0] - gt) / c.size
+        g = np.where((raw > 0) & (raw < 1), g, 0.0)          # the clamp passes no gradient outside (0, 1)
+        assert rel_err(g, fx[f"grad_{i}"]) <= 1e-4
