@@ -150,7 +150,8 @@ class KernelTimer:
         return out
 
 
-def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1, walked=None, from_rects=True):
+def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1, walked=None, from_rects=True, reached=None,
+                      reached_any=None):
     """Bytes one launch must move at least: per-unit figures times the units one
     launch processes.  Preprocess and blend figures of the one-view kernels are
     those of the reference data layout; the binning stages and the two batch
@@ -161,6 +162,8 @@ def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1, walked=None, from_
     last instance one of its pixels blended), not all R sorted instances: at
     this depth complexity a tile is saturated after a few per cent of its list."""
     walked = R if walked is None else walked
+    reached = visible if reached is None else reached              # mean over the views: Gaussians a pixel reached
+    reached_any = visible if reached_any is None else reached_any  # ... in at least one of the step's views
     return {
         "preprocess": 315.0 * visible + 20.0 * (P - visible),
         "depth_order": P * (16.0 + 8.0 + 4.0 + 4 * 16.0),       # bin read, pair write, histogram read, 4 passes
@@ -176,7 +179,9 @@ def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1, walked=None, from_
         "preprocess_bwd": 575.0 * visible,
         # parameters (60 B) and SH row (192 B) read once; per view the 64-byte gradient record, radius and clamp
         # flags in, the screen-space gradient (12 B) out; the 63 parameter gradients written once
-        "preprocess_bwd_batch": P * 60.0 + visible * 192.0 + V * (visible * 69.0 + P * 4.0 + P * 12.0) + P * 252.0,
+        # (the kernel skips, per view, the Gaussians no pixel reached: 12 bytes of radius and hit count are all it
+        # reads of them; parameters and SH row only of those reached in some view)
+        "preprocess_bwd_batch": reached_any * (60.0 + 192.0) + V * (reached * 65.0 + P * 12.0 + P * 12.0) + P * 252.0,
         # parameters and SH row read once; per view the 64-byte record, depth and clamp flags of the rendered
         # Gaussians and radius, tile rectangle and statistics slot (28 B) of all of them out
         "preprocess_batch": P * 60.0 + visible * 192.0 + V * (visible * 69.0 + P * 28.0),
@@ -189,12 +194,12 @@ BOUND = {"tile_count": "hbm", "preprocess_bwd_batch": "hbm", "preprocess_batch":
          "render_fwd": "valu+lds", "render_bwd": "valu+lds+atomics", "preprocess_bwd": "hbm"}
 
 
-def cpu_baseline(P_full, W, H, seed):
+def cpu_baseline(P_full, W, H, seed, translucent=False):
     """The CPU checker on one whole view of the same scene (camera 0)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gs_oracle
     import synth
-    sc = synth.street_scene(P_full, W, H, seed=seed)
+    sc = synth.street_scene(P_full, W, H, seed=seed, translucent=translucent)
     gt = np.random.default_rng(0).random((3, H, W)).astype(np.float32)
     t0 = time.time()
     f = gs_oracle.forward_from_scene(sc, antialiasing=True)
@@ -208,6 +213,78 @@ def cpu_baseline(P_full, W, H, seed):
     return {"value": 1.0 / dt, "unit": "it/s", "cores": gs_oracle.num_threads(), "kind": "port",
             "sample": f"one whole view (camera 0, {P_full} Gaussians, {W}x{H}, R={f.R}): forward + ssim + backward "
                       f"of the OpenMP checker took {dt:.2f} s"}
+
+
+def sort_u64_standalone(n, tile_bits, dev, reps=5):
+    """gsr_sort_pairs_u64_u32 on n (tile << 32 | depth bits, Gaussian index) pairs as the reference's
+    duplicateWithKeys emits them (rasterizer_impl.cu:93-104, sorted on 32 + tile_bits bits at :373-380):
+    milliseconds per sort (HIP events on the launching stream), payload GB/s = n * 12 B / t, and the
+    sort's own traffic rate with 24 B per pair and pass plus the histogram read."""
+    import _gsplat_lib as G
+    L = G.lib()
+    g = torch.Generator(device=dev).manual_seed(7)
+    tiles = torch.randint(0, 1 << tile_bits, (n,), device=dev, generator=g, dtype=torch.int64)
+    depth = (torch.rand(n, device=dev, generator=g) * 40.0 + 0.2).view(torch.int32).to(torch.int64)
+    keys_src = (tiles << 32) | depth
+    vals_src = torch.arange(n, device=dev, dtype=torch.int32)
+    k0, v0 = torch.empty_like(keys_src), torch.empty_like(vals_src)
+    k1, v1 = torch.empty_like(keys_src), torch.empty_like(vals_src)
+    temp = torch.empty(L.gsr_sort_temp_bytes(n), dtype=torch.uint8, device=dev)
+    res = C.c_int(0)
+    end_bit = 32 + tile_bits
+    st = torch.cuda.current_stream().cuda_stream
+    ms = []
+    for i in range(reps + 1):
+        k0.copy_(keys_src)
+        v0.copy_(vals_src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        G.check(L.gsr_sort_pairs_u64_u32(k0.data_ptr(), v0.data_ptr(), k1.data_ptr(), v1.data_ptr(), n, end_bit,
+                                         temp.data_ptr(), temp.numel(), st, C.byref(res)), "sort")
+        e1.record()
+        torch.cuda.synchronize()
+        if i:
+            ms.append(e0.elapsed_time(e1))
+    ko = k0 if res.value == 0 else k1
+    mask = (1 << end_bit) - 1
+    assert bool(((ko[1:] & mask) >= (ko[:-1] & mask)).all()), "stand-alone sort: output not sorted"
+    err = temp[L.gsr_sort_temp_error_offset():L.gsr_sort_temp_error_offset() + 4].view(torch.int32)
+    assert int(err.item()) == 0, "stand-alone sort: look-back error word set"
+    t = float(np.mean(ms))
+    passes = (end_bit + 7) // 8
+    return {"pairs": n, "key_bits": end_bit, "passes": passes, "ms": t, "payload_GBps": n * 12.0 / (t * 1e-3) / 1e9,
+            "hbm_GBps": n * (8.0 + passes * 24.0) / (t * 1e-3) / 1e9,
+            "frac_of_hbm_peak": n * (8.0 + passes * 24.0) / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+
+
+def roofline_entry(dom, ent, achieved_hbm, ab, traffic, ms):
+    """The dominant kernel's roofline.  A blend kernel moves a few per cent of what HBM could in its time:
+    what bounds it is vector-instruction issue, so that is the roofline reported for it (with the HBM
+    floor beside it); the streaming kernels are priced against HBM."""
+    hbm = {"achieved": achieved_hbm, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved_hbm / HBM_PEAK_GBPS}
+    if BOUND.get(dom, "hbm").startswith("valu") and "valu" in ent:
+        v = ent["valu"]
+        return {"kernel": dom, "bound": "valu", "achieved": v["achieved_Ginst_s"], "peak": v["peak_Ginst_s"],
+                "unit": "G wave64-instructions/s", "frac": v["frac"], "traffic": traffic,
+                "algorithmic_bytes_per_launch": ab, "ms_per_launch": ms, "limited_by": BOUND.get(dom),
+                "hbm_floor": hbm, "source": "SQ_INSTS_VALU per launch from profiles/pmc_traffic.json (rocprofv3 --pmc "
+                                            "passes of this command), duration live from HIP events"}
+    return dict({"kernel": dom, "bound": "hbm", "traffic": traffic, "algorithmic_bytes_per_launch": ab,
+                 "ms_per_launch": ms, "limited_by": BOUND.get(dom)}, **hbm)
+
+
+def load_pmc_valu(P, W, H):
+    """Per kernel: wave64 vector instructions per launch, LDS atomics per launch and the shader clock, from
+    the committed PMC summary of this command (empty if none matches the workload)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("_workload") != [P, W, H]:
+            return {}
+        return d.get("_valu", {})
+    except Exception:
+        return {}
 
 
 def load_pmc_traffic(P, W, H):
@@ -268,6 +345,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--views-per-gpu", type=int, default=8, help="views rendered per GPU per step (gradient accumulation)")
+    ap.add_argument("--scene", choices=("street", "translucent"), default="street",
+                    help="street: the headline workload (opaque splats: a tile saturates after ~3 %% of its list); "
+                         "translucent: same geometry, splats half the size and mostly transparent, so that the blend "
+                         "kernels walk ~40 %% of every tile list (reported as extras.translucent by the default run)")
     ap.add_argument("--gaussians", type=int, default=6_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -320,7 +401,7 @@ def main():
     P, W, H, V = args.gaussians, args.width, args.height, max(1, args.views_per_gpu)
     seed = 2
     t0 = time.time()
-    sc = synth.street_scene(P, W, H, seed=seed)
+    sc = synth.street_scene(P, W, H, seed=seed, translucent=args.scene == "translucent")
     params = build_params(sc, dev)
     sh_degree = sc["sh_degree"]
     del sc
@@ -492,12 +573,16 @@ def main():
     from_rects = ((gx + 1) * (gy + 1) + passes * 256 + 17) * 4 <= 150 * 1024   # as tile_counts_fit in the library
 
     # workload counters of this rank's views (outside the timed region)
-    vis_l, R_l, pairs_l = [], [], []
+    vis_l, R_l, pairs_l, reached_l = [], [], [], []
+    reached_any_t = torch.zeros(P, dtype=torch.bool, device=dev)
     with torch.no_grad():
         for rs, _ in views:
             o = render_params(params, rs)
             vis_l.append(int((o[1] > 0).sum().item()))
             pairs_l.append(int(o[4].sum(dtype=torch.int64).item()))   # (pixel, Gaussian) pairs the forward blend tested
+            hit = (o[4] > 0) & (o[1] > 0)                             # Gaussians some pixel reached in this view
+            reached_l.append(int(hit.sum().item()))
+            reached_any_t |= hit
         from diff_gaussian_rasterization import _C as RC
         e = torch.Tensor([])
         import ctypes
@@ -518,6 +603,7 @@ def main():
             walked_l.append(int(n.reshape(gy, 16, gx, 16).amax(dim=(1, 3)).sum(dtype=torch.int64).item()))
     visible, R, pairs = float(np.mean(vis_l)), float(np.mean(R_l)), float(np.mean(pairs_l))
     walked = float(np.mean(walked_l))
+    reached, reached_any = float(np.mean(reached_l)), float(reached_any_t.sum().item())
 
     extras = {}
     if rank == 0 and world == 1 and not args.fwd_only and not args.no_extras:
@@ -588,6 +674,9 @@ def main():
             extras.setdefault("optimizer_step_ms", {})[name] = 1e3 / timed(lambda: fn(opt), 10)
             del opt
 
+        # the stand-alone 64-bit sort on as many pairs as a view has instances
+        extras["sort_u64"] = sort_u64_standalone(int(R), (gx * gy).bit_length(), dev)
+
         # simple-knn initialisation (scene/gaussian_model.py:533) over the scene's 6 M points
         from simple_knn._C import distCUDA2
         pts = params["xyz"].detach()
@@ -610,13 +699,34 @@ def main():
             "fused": 1e3 / timed(lambda: add_densification_stats(radii0, g2, acc, den, mx), 10),
             "torch_reference_formulation": 1e3 / timed(stats_reference, 10)}
 
+    if rank == 0 and world == 1 and not args.fwd_only and not args.no_extras and args.scene == "street" \
+            and use_params:
+        # The same step on the translucent variant of the scene, where the blend kernels dominate: a child
+        # process (this one keeps its GPU state and waits), a few steps, its JSON line condensed.
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--scene", "translucent", "--steps", "6", "--warmup", "2",
+               "--no-extras", "--no-cpu-baseline", "--gaussians", str(P), "--width", str(W), "--height", str(H),
+               "--views-per-gpu", str(V), "--streams", str(args.streams)]
+        try:
+            cp = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            d = json.loads(cp.stdout.decode().strip().splitlines()[-1])
+            extras["translucent"] = {
+                "it_s": d["value"], "ms_per_step": d["ms_per_step"], "one_stream_it_s": d.get("one_stream_it_s"),
+                "visible_mean": d["config"]["visible_mean"], "num_rendered_mean": d["config"]["num_rendered_mean"],
+                "instances_walked_mean": d["config"]["instances_walked_mean"],
+                "pairs_tested_mean": d["config"]["pairs_tested_mean"],
+                "kernels_ms": {k: round(v["ms"], 4) for k, v in d["kernels"].items()},
+                "roofline": d["roofline"]}
+        except Exception as ex:
+            extras["translucent"] = {"error": repr(ex)}
+
     if rank == 0:
         traffic = load_pmc_traffic(P, W, H)
         per_kernel = {}
         launches = lambda k: 1 if k in KernelTimer.PER_STEP else V          # per step
 
         def alg(k):
-            return algorithmic_bytes(k, P, visible, R, H * W, passes, V, walked, from_rects)
+            return algorithmic_bytes(k, P, visible, R, H * W, passes, V, walked, from_rects, reached, reached_any)
 
         for k, ms in kernels.items():
             ab = alg(k)
@@ -631,6 +741,19 @@ def main():
         dom = max((k for k in kernels if alg(k)), key=lambda k: kernels[k] * launches(k))
         ab = alg(dom)
         achieved = ab / (kernels[dom] * 1e-3) / 1e9
+        # Vector-instruction issue: wave64 instructions a launch executes (SQ_INSTS_VALU of the committed PMC passes
+        # of this command) over the live duration, against 1024 SIMDs x 0.5 instructions per clock (a wave64
+        # instruction issues over 2 cycles on a 32-lane SIMD) at the clock the counters show.
+        valu = load_pmc_valu(P, W, H)
+        for k, ent in per_kernel.items():
+            if k in valu and args.scene == "street":
+                v = valu[k]
+                clk = v.get("clock_GHz") or 2.4
+                peak = 1024 * 0.5 * clk      # G wave-instructions / s
+                rate = v["valu_insts"] / (ent["ms"] * 1e-3) / 1e9
+                ent["valu"] = {"wave_insts_per_launch": v["valu_insts"], "achieved_Ginst_s": rate, "peak_Ginst_s": peak,
+                               "frac": rate / peak, "lds_atomic_insts": v.get("lds_atomic_insts"),
+                               "insts_per_tested_pair": v["valu_insts"] * 64.0 / pairs if k.startswith("render") and pairs else None}
         views_total = world * V * args.steps
         res = {
             "metric": "render FPS (forward only)" if args.fwd_only else
@@ -645,7 +768,8 @@ def main():
             "host_blocked_ms_per_step": host_wait_ms if batch_fwd else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"street scene, {P} Gaussians SH3 + 4 reps, {W}x{H}, antialiasing; a step = {V} views "
+            "config": {"workload": f"{args.scene if args.scene != 'street' else 'street scene'}"
+                                   f"{' street scene (small, mostly transparent splats)' if args.scene == 'translucent' else ''}, {P} Gaussians SH3 + 4 reps, {W}x{H}, antialiasing; a step = {V} views "
                                    f"per GPU (different cameras, gradients accumulate)" +
                                    (", forward only" if args.fwd_only else ", each fwd + fused-ssim loss + bwd, then one "
                                     "gradient all-reduce when n_gpus > 1; no optimizer"),
@@ -655,19 +779,19 @@ def main():
                                 "PyTorch L1 / clamp around fused_ssim + reps L1 (as train.py)"),
                        "gaussians": P, "views_per_gpu_per_step": V, "visible_mean": visible, "num_rendered_mean": R,
                        "pairs_tested_mean": pairs, "tile_list_mean": R / (gx * gy),
-                       "instances_walked_mean": walked,
+                       "instances_walked_mean": walked, "reached_mean": reached, "reached_in_any_view": reached_any,
                        "image": [W, H], "parallelism": f"view-sharded x{world}, full replicas" if world > 1 else "single GPU",
                        "collective_backend": (backend if world > 1 else None)},
-            "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic.get(dom),
-                         "algorithmic_bytes_per_launch": ab, "ms_per_launch": kernels[dom],
-                         "limited_by": BOUND.get(dom)},
+            "roofline": roofline_entry(dom, per_kernel[dom], achieved, ab, traffic.get(dom), kernels[dom]),
             "kernels": per_kernel,
             "kernels_measured_in": ("a pass with one view after the other, after the timed region (same process, same "
                                     "workload)" if overlapping else "the timed region"),
-            # the reference's sort (R pairs of u64 key + u32 value) is done here by the depth ordering of the
-            # Gaussians plus the sort of the instances on their tile id: payload rate over both
-            "sort_GBps": (R * 12.0 / ((kernels["sort"] + kernels["depth_order"]) * 1e-3) / 1e9) if R else None,
+            # What the reference does with duplicateWithKeys + SortPairs (R pairs of u64 key + u32 value) is done
+            # here by the depth ordering of the Gaussians, the emission that partitions on the high tile digit and
+            # the segmented pass on the low one: payload rate R x 12 B over ALL of that (emission included: a
+            # lower bound for the sort alone).  `sort_u64` (extras) is the stand-alone 64-bit sort of the C ABI.
+            "sort_GBps": (R * 12.0 / ((kernels["sort"] + kernels["depth_order"] + kernels["emit_keys"]) * 1e-3) / 1e9)
+                         if R else None,
             "sort_hbm_GBps": (algorithmic_bytes("sort", P, visible, R, H * W, passes, V, walked, from_rects) /
                               (kernels["sort"] * 1e-3) / 1e9) if R else None,
         }
@@ -675,6 +799,11 @@ def main():
             res["kernels_in_timed_region_ms"] = kernels_overlapped
             res["one_stream_it_s"] = one_stream_it_s
         res.update(extras)
+        # the like-for-like numbers next to the headline: the same iteration one view at a time, and through the
+        # unchanged reference signature (what train.py / render.py get as a drop-in)
+        for k in ("single_view_it_s", "reference_api_it_s", "render_fps", "render_fps_reference_api"):
+            if k in extras:
+                res["config"][k] = extras[k]
         if world > 1 and reducer_ms:
             nbytes = float(sum(p.grad.numel() * 4 for p in leaves))
             res["allreduce"] = {
@@ -689,7 +818,7 @@ def main():
                             if allreduce_alone_ms else None}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(P, W, H, seed)
+                res["cpu_baseline"] = cpu_baseline(P, W, H, seed, args.scene == "translucent")
             except Exception as ex:  # the checker is optional for the measurement itself
                 res["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(res), flush=True)

@@ -183,29 +183,34 @@ class SortErrorWords:
     """Where the sort's error word of every forward call lands without making the host wait.
 
     The look-back spins of the radix sort are bounded; a tripped limit leaves an error word on the
-    device and an invalid instance list.  Each `rasterize_gaussians` call hands stage 2 one pinned
-    host word (GsrForwardOut.sort_error_host) and records an event behind it; every later call
-    into the rasterizer looks at the words whose event has completed and raises if one is set, so
-    the failure surfaces at the next call after the GPU got there instead of never."""
+    device and an invalid instance list.  Each `rasterize_gaussians` call hands stage 2 one word of
+    pinned host memory (GsrForwardOut.sort_error_host), preset to all ones; the last kernel of the
+    forward stores the error word there.  Every later call into the rasterizer looks at the words
+    that have arrived and raises if one is set, so the failure surfaces at the next call after the
+    GPU got there instead of never.  No events, no copies, nothing the stream waits on."""
 
-    SLOTS = 256
+    SLOTS = 1024
+    UNSET = -1   # all ones: never stored by the library
 
     def __init__(self):
         self.words = None
-        self.pending = []   # (event, slot)
+        self.view = None     # numpy view of the pinned words
+        self.pending = []
         self.free = list(range(self.SLOTS))
 
     def poll(self, block=False):
-        keep = []
-        bad = False
-        for ev, slot in self.pending:
-            if block:
-                ev.synchronize()
-            if block or ev.query():
-                bad = bad or int(self.words[slot]) != 0
-                self.free.append(slot)
+        if not self.pending:
+            return
+        if block:
+            torch.cuda.synchronize()
+        keep, bad = [], False
+        for slot in self.pending:
+            v = int(self.view[slot])
+            if v == self.UNSET:
+                keep.append(slot)
             else:
-                keep.append((ev, slot))
+                bad = bad or v != 0
+                self.free.append(slot)
         self.pending = keep
         if bad:
             raise RuntimeError("rasterize_gaussians: " + lib().gsr_status_string(-6).decode() +
@@ -213,20 +218,22 @@ class SortErrorWords:
                                "are invalid")
 
     def take(self):
-        """Address of a zeroed host word for the next stage-2 call, and its slot."""
+        """Address of a preset host word for the next stage-2 call, and its slot."""
         if self.words is None:
-            self.words = torch.zeros(self.SLOTS, dtype=torch.int32).pin_memory()
+            self.words = torch.full((self.SLOTS,), self.UNSET, dtype=torch.int32).pin_memory()
+            self.view = self.words.numpy()
         self.poll()
         if not self.free:
             self.poll(block=True)
         slot = self.free.pop()
-        self.words[slot] = 0
+        self.view[slot] = self.UNSET
         return self.words.data_ptr() + 4 * slot, slot
 
-    def submitted(self, slot, device):
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(device))
-        self.pending.append((ev, slot))
+    def submitted(self, slot):
+        self.pending.append(slot)
+
+    def release(self, slot):
+        self.free.append(slot)
 
 
 sort_errors = SortErrorWords()

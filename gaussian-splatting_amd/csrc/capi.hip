@@ -165,27 +165,29 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
     }
     GSR_TRY(launch_render_fwd(*s, *o, g, im, point_list, st));
     mark(s, GSR_EV_RENDER, st);
-    if (s->P > 0) {
-        GSR_TRY(launch_finish_gstat(g, s->P, o->gauss_sum, o->gauss_count, st));
-        mark(s, GSR_EV_FINISH, st);
-    }
     // The sorts' look-back spins are bounded; a tripped limit sets an error word in the sort's temp area.
-    // With debug the call waits and reports it; otherwise the word goes to the caller's host word in
-    // stream order (no wait here), or stays unread if the caller gave none.
-    if (R > 0 && s->P > 0 && (debug || o->sort_error_host)) {
+    // With debug the call waits and reports it; otherwise the last kernel stores the word to the caller's
+    // host word in stream order (nothing here waits), or it stays unread if the caller gave none.
+    const uint32_t* sort_err = nullptr;
+    if (R > 0 && s->P > 0) {
         const SortTemp t = sort_temp_view(bin_view(binning_buffer, (size_t)R).sort_temp, 1, 0);
-        if (g_inject_sort_error.load(std::memory_order_relaxed) &&
-            hipMemsetAsync(t.err, 1, 1, st) != hipSuccess)
+        sort_err = t.err;
+        if (g_inject_sort_error.load(std::memory_order_relaxed) && hipMemsetAsync(t.err, 1, 1, st) != hipSuccess)
             return GSR_ERR_HIP;
-        if (debug) {
-            uint32_t err = 0;
-            if (hipMemcpyAsync(&err, t.err, sizeof(err), hipMemcpyDeviceToHost, st) != hipSuccess) return GSR_ERR_HIP;
-            if (hipStreamSynchronize(st) != hipSuccess) return GSR_ERR_HIP;
-            if (err) return GSR_ERR_SORT;
-        } else if (hipMemcpyAsync(o->sort_error_host, t.err, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) {
-            return GSR_ERR_HIP;
-        }
     }
+    if (s->P > 0) {
+        GSR_TRY(launch_finish_gstat(g, s->P, o->gauss_sum, o->gauss_count, sort_err, debug ? nullptr : o->sort_error_host, st));
+        mark(s, GSR_EV_FINISH, st);
+    } else if (o->sort_error_host) {
+        *o->sort_error_host = 0;  // nothing was sorted, nothing runs: the host word is set here
+    }
+    if (debug && sort_err) {
+        uint32_t err = 0;
+        if (hipMemcpyAsync(&err, sort_err, sizeof(err), hipMemcpyDeviceToHost, st) != hipSuccess) return GSR_ERR_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess) return GSR_ERR_HIP;
+        if (err) return GSR_ERR_SORT;
+    }
+    if (debug && o->sort_error_host) *o->sort_error_host = 0;  // reported (or clean) through the return value
     return GSR_OK;
 }
 

@@ -649,9 +649,14 @@ __global__ void __launch_bounds__(256) keys64_kernel(const uint32_t* tile_keys, 
     out[i] = ((uint64_t)tile_keys[i] << 32) | bin[point_list[i]].z;
 }
 
+// Also the last kernel of a forward pass: it hands the sort's error word to the caller's host word
+// (device-accessible pinned memory; a system-scope store, no copy engine, nothing for the stream to wait on).
 __global__ void __launch_bounds__(256) finish_gstat_kernel(int P, const float2* gstat, float* gauss_sum,
-                                                           int* gauss_count) {
+                                                           int* gauss_count, const uint32_t* sort_err,
+                                                           uint32_t* sort_err_host) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && sort_err_host)
+        __hip_atomic_store(sort_err_host, sort_err ? *sort_err : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (i >= P) return;
     const float2 v = gstat[i];
     gauss_sum[i] = v.x;
@@ -766,9 +771,10 @@ hipError_t launch_keys64(const GeomBuf& g, const uint32_t* tile_keys, const uint
     return hipGetLastError();
 }
 
-hipError_t launch_finish_gstat(const GeomBuf& g, int P, float* gauss_sum, int* gauss_count, hipStream_t st) {
+hipError_t launch_finish_gstat(const GeomBuf& g, int P, float* gauss_sum, int* gauss_count, const uint32_t* sort_err,
+                               uint32_t* sort_err_host, hipStream_t st) {
     hipLaunchKernelGGL(finish_gstat_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, g.gstat, gauss_sum,
-                       gauss_count);
+                       gauss_count, sort_err, sort_err_host);
     return hipGetLastError();
 }
 

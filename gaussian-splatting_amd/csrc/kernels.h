@@ -80,7 +80,10 @@ hipError_t launch_tile_ranges(const uint32_t* keys, int64_t R, uint2* ranges, in
 // (tile << 32 | depth bits) of every sorted instance, as the reference's sort keys.
 hipError_t launch_keys64(const GeomBuf& g, const uint32_t* tile_keys, const uint32_t* point_list, int64_t R,
                          uint64_t* out, hipStream_t st);
-hipError_t launch_finish_gstat(const GeomBuf& g, int P, float* gauss_sum, int* gauss_count, hipStream_t st);
+// Unpacks the statistics; as the last kernel of the forward it also stores *sort_err (0 if null) to
+// *sort_err_host (device-accessible host memory, may be null).
+hipError_t launch_finish_gstat(const GeomBuf& g, int P, float* gauss_sum, int* gauss_count, const uint32_t* sort_err,
+                               uint32_t* sort_err_host, hipStream_t st);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);
 
 // Returns the index (0/1) of the buffer pair that holds the sorted result.

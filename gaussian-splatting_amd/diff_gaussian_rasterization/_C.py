@@ -111,8 +111,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         try:
             check(L.gsr_forward_stage2(C.byref(s), C.byref(o), R, ptr(binning), binning.numel(), st),
                   "rasterize_gaussians (stage 2)")
-        finally:
-            sort_errors.submitted(slot, dev)
+        except Exception:
+            sort_errors.release(slot)    # the call reported its failure itself
+            raise
+        sort_errors.submitted(slot)
     return (R, out_color, radii, geom, binning, img, out_invdepth, accum_alpha, gauss_sum, gauss_count, last_contr,
             out_depths, out_reps)
 

@@ -121,9 +121,16 @@ def street_camera(width, height, cam_index=0, n_cams=1, fovx_deg=60.0):
     return make_camera(width, height, math.radians(fovx_deg), eye, (0.0, 0.5, 20.0))
 
 
-def street_scene(P, width, height, seed=2, sh_coeffs=16, dim=4, fovx_deg=60.0, cam_index=0, n_cams=1):
+def street_scene(P, width, height, seed=2, sh_coeffs=16, dim=4, fovx_deg=60.0, cam_index=0, n_cams=1,
+                 translucent=False, opacity_logit_mean=-2.0, scale_factor=0.5):
     """Outdoor-capture-like: 70 % of the points in a slab in front of the
-    camera, 30 % Gaussian clutter around it; log-normal anisotropic scales."""
+    camera, 30 % Gaussian clutter around it; log-normal anisotropic scales.
+
+    translucent: the same geometry with smaller and much more transparent splats
+    (opacity = sigmoid(N(opacity_logit_mean, 1)), scales times scale_factor), as in a
+    scene early in training or one made of thin structures: a pixel then blends
+    many Gaussians before it saturates, so the blend kernels walk a large part of
+    every tile list instead of the first few per cent."""
     rng = np.random.default_rng(seed)
     n_slab = int(0.7 * P)
     slab = np.empty((n_slab, 3))
@@ -137,6 +144,11 @@ def street_scene(P, width, height, seed=2, sh_coeffs=16, dim=4, fovx_deg=60.0, c
     base = 0.02 * np.exp(0.8 * rng.standard_normal((P, 1)))
     scales = (base * np.exp(0.35 * rng.standard_normal((P, 3)))).astype(np.float32)
     rot, opac, sh, reps = _common_attrs(rng, P, sh_coeffs, dim)
+    if translucent:
+        rng2 = np.random.default_rng(seed + 1000)
+        scales = (scales * np.float32(scale_factor)).astype(np.float32)
+        opac = (1.0 / (1.0 + np.exp(-(opacity_logit_mean + rng2.standard_normal(P))))).astype(np.float32)
+        opac = np.clip(opac, 0.005, 0.98).astype(np.float32)
     cam = street_camera(width, height, cam_index, n_cams, fovx_deg)
     return dict(means3D=xyz, scales=scales, rotations=rot, opacities=opac.reshape(P, 1), shs=sh, reps=reps,
                 camera=cam, sh_degree=int(round(math.sqrt(sh_coeffs))) - 1)

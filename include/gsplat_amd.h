@@ -133,11 +133,14 @@ typedef struct {
                                 < 0 there means "not known" and all P are ordered. */
     int preprocessed;        /* nonzero: geom_buffer, radii and out_depths were filled by gsr_preprocess_batch for
                                 this view; gsr_forward_stage1 then only runs the prefix sums */
-    uint32_t* sort_error_host; /* NULL, or HOST memory (pinned, so that the copy is asynchronous) that receives the
-                                radix sort's error word at the end of gsr_forward_stage2, in stream order: nonzero
-                                once the stream has passed that point = a look-back did not complete and the instance
-                                list is not valid (what GSR_ERR_SORT reports when scene->debug makes the call wait).
-                                The word must stay valid until the stream has passed the call. */
+    uint32_t* sort_error_host; /* NULL, or a word of host memory that the GPU can write (hipHostMalloc / pinned):
+                                the last kernel of gsr_forward_stage2 stores the radix sort's error word there, in
+                                stream order and without making the call wait.  Nonzero = a look-back did not
+                                complete within its spin limit and the instance list is not valid (what
+                                GSR_ERR_SORT reports when scene->debug makes the call wait; then 0 is stored).
+                                A caller that sets the word to a value the library never stores (all ones) before
+                                the call sees from the word alone when the GPU has passed the call.  The word must
+                                stay valid until then. */
 } GsrForwardOut;
 
 /* Gradients.  Inputs are the three per-pixel gradients; every output is fully

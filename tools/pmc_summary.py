@@ -86,6 +86,30 @@ def main():
         if all(d in traffic for d, _ in parts if d not in ("sort:scan", "sort:hist")):
             simple[name] = sum(traffic.get(d, 0.0) * n for d, n in parts)
     out_d = {k: simple[k] for k in sorted(simple)}
+    # vector-instruction counts and the shader clock (GRBM_GUI_ACTIVE is summed over the 8 XCDs) for bench.py's
+    # issue-rate roofline; durations come from the trace pass (kernel_stats, ns)
+    dur_ns = {}
+    for path in sorted(glob.glob(os.path.join(SRC, "trace", "**", "*kernel_stats.csv"), recursive=True),
+                       key=os.path.getmtime)[-1:]:
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                k = short(row["Name"])
+                if k and k not in ("sort:onesweep", "sort:hist"):
+                    dur_ns[k] = float(row["AverageNs"])
+    valu = {}
+    for k in acc:
+        iv = acc[k].get("SQ_INSTS_VALU")
+        if not iv or ":" in k:
+            continue
+        ent = {"valu_insts": sum(iv) / len(iv)}
+        la = acc[k].get("SQ_INSTS_LDS_ATOMIC")
+        if la:
+            ent["lds_atomic_insts"] = sum(la) / len(la)
+        ga = acc[k].get("GRBM_GUI_ACTIVE")
+        if ga and k in dur_ns:
+            ent["clock_GHz"] = (sum(ga) / len(ga)) / 8.0 / dur_ns[k]
+        valu[k] = ent
+    out_d["_valu"] = valu
     out_d["_workload"] = [6000000, 1920, 1080]   # bench.py defaults, which tools/collect_pmc.sh runs
     out_d["_note"] = "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB, mean over the launches of the PMC passes"
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
