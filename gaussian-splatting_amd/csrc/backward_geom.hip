@@ -38,7 +38,7 @@ struct PreBwdArgs {
     const float* cov3D;  // the precomputed 3D covariance, if that is what the caller gave
     CamPtrs cam;
     const int* radii;
-    const float2* gstat;  // the forward's per-Gaussian (sum of T, pixels that reached it)
+    const GStat* gstat;   // the forward's per-Gaussian (sum of T, pixels that reached it)
     const uint8_t* clamped;
     const GradRec* acc;
     int has_invdepth;
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(256, PRE_BWD_WAVES) preprocess_bwd_kernel(cons
     // forward (backward.cu:592-611 walks the pairs the forward blended).  One that no pixel
     // reached, hidden behind saturated tiles, say, has an all-zero GradRec and with it zero
     // gradients: it is treated like one that was culled, and its GradRec is not read.
-    const bool rendered = live && a.radii[live ? idx : 0] > 0 && a.gstat[live ? idx : 0].y > 0.0f;
+    const bool rendered = live && a.radii[live ? idx : 0] > 0 && a.gstat[live ? idx : 0].count != 0u;
     float* lds = reinterpret_cast<float*>(s_sh + w * WAVE_LDS);
     const uint64_t rows = __ballot(rendered);
     if (MODE == SH_CAT16) {
@@ -333,7 +333,7 @@ struct BatchView {
     float tanx, tany;
     int W, H, aa, has_invdepth;
     const int* radii;
-    const float2* gstat;
+    const GStat* gstat;
     const uint8_t* clamped;
     const GradRec* acc;
     float* dL_dmeans2D;  // [P,3] of this view, or null
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
     uint32_t seen = 0;  // bit v: rendered in view v and reached by a pixel there (else its GradRec is zero)
     for (int v = 0; v < b.nviews; ++v) {
         if (!live) break;
-        if (b.v[v].radii[i] > 0 && b.v[v].gstat[i].y > 0.0f) {
+        if (b.v[v].radii[i] > 0 && b.v[v].gstat[i].count != 0u) {
             seen |= 1u << v;
         } else if (b.v[v].dL_dmeans2D) {  // the screen-space gradient of a view is per view: zero here
             float* m2 = b.v[v].dL_dmeans2D + 3 * i;
@@ -526,10 +526,10 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
 // in the forward.  The others are never read (see `rendered` / `seen` above), so a view costs
 // 8 bytes read per Gaussian and 64 written per reached one instead of a 64-byte fill of all.
 // One lane per Gaussian: the hit counts are read coalesced, and only about one record in ten is written.
-__global__ void __launch_bounds__(256) clear_reached_kernel(int P, const float2* gstat, GradRec* acc) {
+__global__ void __launch_bounds__(256) clear_reached_kernel(int P, const GStat* gstat, GradRec* acc) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    if (gstat[i].y > 0.0f) {
+    if (gstat[i].count != 0u) {
         float4* r = reinterpret_cast<float4*>(acc + i);
         r[0] = r[1] = r[2] = r[3] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -542,12 +542,12 @@ hipError_t launch_clear_reached(int P, const GeomBuf& g, GradRec* acc, hipStream
 
 // dL/dmeans2D of one view straight from its GradRec (the only per-Gaussian
 // gradient a caller needs per view: the densification statistics read it).
-__global__ void __launch_bounds__(256) means2d_grad_kernel(int P, const float2* gstat, const GradRec* acc,
+__global__ void __launch_bounds__(256) means2d_grad_kernel(int P, const GStat* gstat, const GradRec* acc,
                                                            float* dL_dmeans2D) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     float2 g = make_float2(0.f, 0.f);
-    if (gstat[i].y > 0.0f) g = *reinterpret_cast<const float2*>(acc + i);  // records nobody reached hold no data
+    if (gstat[i].count != 0u) g = *reinterpret_cast<const float2*>(acc + i);  // records nobody reached hold no data
     dL_dmeans2D[3 * (size_t)i] = g.x;
     dL_dmeans2D[3 * (size_t)i + 1] = g.y;
     dL_dmeans2D[3 * (size_t)i + 2] = 0.f;

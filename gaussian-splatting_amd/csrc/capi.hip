@@ -62,6 +62,7 @@ size_t gsr_sort_temp_error_offset(void) {
     char* const z = (char*)4096;
     return (size_t)((char*)sort_temp_view(z, 1, 0).err - z);
 }
+void gsr_test_force_wide_sort_status(int on) { sort_set_force_wide(on != 0); }
 void gsr_test_inject_sort_error(int on) { g_inject_sort_error.store(on ? 1 : 0, std::memory_order_relaxed); }
 size_t gsr_sort_temp_bytes(int64_t n) { return sort_temp_view(nullptr, (size_t)(n > 0 ? n : 1), SORT_MAX_PASSES).bytes; }
 
@@ -96,7 +97,7 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
     int rc = check_scene(s);
     if (rc != GSR_OK) return rc;
     if (!o || R < 0) return GSR_ERR_ARG;
-    if (R >= (1ll << 30)) return GSR_ERR_OVERFLOW;
+    if (R > (int64_t)INT32_MAX) return GSR_ERR_OVERFLOW;  // the reference holds this count in an int (rasterizer_impl.cu:338)
     if (!o->out_color || !o->accum_alpha || !o->last_contr_gauss || !o->image_buffer) return GSR_ERR_ARG;
     if (s->DIM > 0 && !o->out_reps) return GSR_ERR_ARG;
     if (o->image_bytes < gsr_image_bytes(s->W, s->H)) return GSR_ERR_BUFFER;
@@ -341,7 +342,7 @@ int gsr_sort_pairs_u64_u32(uint64_t* keys0, uint32_t* vals0, uint64_t* keys1, ui
     if (n < 0 || end_bit < 0 || end_bit > 64 || !result_buffer) return GSR_ERR_ARG;
     *result_buffer = 0;
     if (n == 0 || end_bit == 0) return GSR_OK;
-    if (n >= (1ll << 30)) return GSR_ERR_OVERFLOW;
+    if (n > (int64_t)INT32_MAX) return GSR_ERR_OVERFLOW;
     if (!keys0 || !vals0 || !keys1 || !vals1 || !temp) return GSR_ERR_ARG;
     if (temp_bytes < gsr_sort_temp_bytes(n)) return GSR_ERR_BUFFER;
     uint64_t* k[2] = {keys0, keys1};
@@ -526,7 +527,7 @@ const char* gsr_status_string(int status) {
         case GSR_OK: return "ok";
         case GSR_ERR_ARG: return "invalid argument";
         case GSR_ERR_DIM: return "unsupported number of reps channels (supported: 0, 4)";
-        case GSR_ERR_OVERFLOW: return "too many Gaussian/tile instances (>= 2^30)";
+        case GSR_ERR_OVERFLOW: return "too many Gaussian/tile instances (more than 2^31 - 1)";
         case GSR_ERR_BUFFER: return "caller buffer too small";
         case GSR_ERR_HIP: return "HIP runtime error";
         case GSR_ERR_SORT: return "radix sort look-back did not complete";

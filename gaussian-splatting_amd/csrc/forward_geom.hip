@@ -31,7 +31,7 @@ struct PreArgs {
     SplatRec* rec;
     float* cov3D;
     uint4* bin;
-    float2* gstat;
+    GStat* gstat;
     uint8_t* clamped;
     uint32_t* block_sums;
     uint32_t* vis_sums;
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs
         }
         a.radii[idx] = radius;
         a.bin[idx] = bin;
-        a.gstat[idx] = make_float2(0.0f, 0.0f);
+        a.gstat[idx] = GStat{0.0f, 0u};
     }
     // tiles touched by this block of 256 Gaussians
     const uint32_t ws = wave_sum_u32(tiles);
@@ -143,7 +143,7 @@ struct FwdBatchView {
     float* out_depths;
     SplatRec* rec;
     uint4* bin;
-    float2* gstat;
+    GStat* gstat;
     uint8_t* clamped;
     uint32_t* block_sums;
     uint32_t* vis_sums;
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(PRE_BLOCK, 2) preprocess_fwd_batch_kernel(cons
             }
             bv.radii[i] = radius;
             bv.bin[i] = bin;
-            bv.gstat[i] = make_float2(0.0f, 0.0f);
+            bv.gstat[i] = GStat{0.0f, 0u};
         }
         const uint32_t ws = wave_sum_u32(tiles);
         const uint32_t wv = (uint32_t)__popcll(__ballot(tiles > 0));
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* sum
         block_sums[nb] = (uint32_t)carry;
         if (blockIdx.x == 0) {
             total[0] = carry;
-            total[1] = carry >= (1ull << 30) ? 1 : 0;
+            total[1] = carry > 0x7fffffffull ? 1 : 0;
         } else {
             total[2] = carry;
         }
@@ -651,16 +651,16 @@ __global__ void __launch_bounds__(256) keys64_kernel(const uint32_t* tile_keys, 
 
 // Also the last kernel of a forward pass: it hands the sort's error word to the caller's host word
 // (device-accessible pinned memory; a system-scope store, no copy engine, nothing for the stream to wait on).
-__global__ void __launch_bounds__(256) finish_gstat_kernel(int P, const float2* gstat, float* gauss_sum,
+__global__ void __launch_bounds__(256) finish_gstat_kernel(int P, const GStat* gstat, float* gauss_sum,
                                                            int* gauss_count, const uint32_t* sort_err,
                                                            uint32_t* sort_err_host) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0 && sort_err_host)
         __hip_atomic_store(sort_err_host, sort_err ? *sort_err : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (i >= P) return;
-    const float2 v = gstat[i];
-    gauss_sum[i] = v.x;
-    gauss_count[i] = (int)v.y;
+    const GStat v = gstat[i];
+    gauss_sum[i] = v.sum;
+    gauss_count[i] = (int)v.count;
 }
 
 // rasterizer_impl.cu:54-66

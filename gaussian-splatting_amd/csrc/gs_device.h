@@ -320,6 +320,16 @@ struct __attribute__((aligned(16))) SplatRec {
 };
 static_assert(sizeof(SplatRec) == 64, "SplatRec must be 64 bytes");
 
+// The fork's per-Gaussian statistics (forward.cu:431-432) while the forward blend accumulates them:
+// the sum of the transmittances as a float, the number of tested pixels as an integer (the reference
+// counts with an int atomicAdd; a float count would stop being exact at 2^24 pixels per Gaussian).
+// One 8-byte slot: a workgroup updates both with two adjacent atomics.
+struct __attribute__((aligned(8))) GStat {
+    float sum;
+    uint32_t count;
+};
+static_assert(sizeof(GStat) == 8, "GStat must be 8 bytes");
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 constexpr int PRE_BLOCK = 256;  // Gaussians per preprocess / key-emit workgroup
@@ -365,10 +375,17 @@ struct SortTemp {
     uint32_t* ghist;    // [SORT_MAX_PASSES][256] digit histograms, then exclusive bases
     uint32_t* ticket;   // [SORT_MAX_PASSES]
     uint32_t* err;      // [1]
-    uint32_t* status;   // [passes][tiles][256]
+    void* status;       // [passes][tiles][256] look-back words: u32 (2 flag bits + 30-bit count), or u64 when wide
+    bool wide;
     size_t zero_bytes;  // bytes from ghist that must be zero before a sort
     size_t bytes;
 };
+
+// A look-back status word carries a prefix count of up to n: 30 bits beside the two flag bits of a
+// 32-bit word, so sorts of 2^30 pairs and more use 64-bit words (twice the status traffic, which is
+// 1/16 of a pass's data).  sort_force_wide(): test hook that selects the 64-bit words at any size.
+bool sort_force_wide();
+inline bool sort_status_wide(size_t n) { return n >= ((size_t)1 << 30) || sort_force_wide(); }
 
 inline SortTemp sort_temp_view(void* base, size_t n, int passes) {
     SortTemp v;
@@ -379,7 +396,8 @@ inline SortTemp sort_temp_view(void* base, size_t n, int passes) {
     v.ghist = (uint32_t*)take(SORT_MAX_PASSES * 256 * sizeof(uint32_t));
     v.ticket = (uint32_t*)take(SORT_MAX_PASSES * sizeof(uint32_t));
     v.err = (uint32_t*)take(sizeof(uint32_t));
-    v.status = (uint32_t*)take((size_t)passes * tiles * 256 * sizeof(uint32_t));
+    v.wide = sort_status_wide(n);
+    v.status = take((size_t)passes * tiles * 256 * (v.wide ? sizeof(uint64_t) : sizeof(uint32_t)));
     v.zero_bytes = off;
     v.bytes = off;
     return v;

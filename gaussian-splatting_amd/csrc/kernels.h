@@ -14,7 +14,7 @@ struct GeomBuf {
     SplatRec* rec;        // [P]
     float* cov3D;         // [P,6]
     uint4* bin;           // [P] {x0 | y0<<16, w | h<<16, depth bits, tiles}
-    float2* gstat;        // [P] (sum of T, hit count as float), accumulated by the forward blend
+    GStat* gstat;         // [P] (sum of T, hit count), accumulated by the forward blend
     uint8_t* clamped;     // [P]
     uint32_t* block_sums; // [nblocks+1] tiles per block of 256 Gaussians in index order (gives the total)
     uint32_t* vis_sums;   // [nblocks+1] Gaussians with instances per block, then exclusive offsets
@@ -36,7 +36,7 @@ inline GeomBuf geom_buf(const void* base, size_t P) {
     v.rec = (SplatRec*)take(P * sizeof(SplatRec));
     v.cov3D = (float*)take(P * 6 * sizeof(float));
     v.bin = (uint4*)take(P * sizeof(uint4));
-    v.gstat = (float2*)take(P * sizeof(float2));
+    v.gstat = (GStat*)take(P * sizeof(GStat));
     v.clamped = (uint8_t*)take(P);
     v.block_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));
     v.vis_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));
@@ -63,6 +63,7 @@ struct __attribute__((aligned(16))) GradRec {
 static_assert(sizeof(GradRec) == 64, "GradRec must be 64 bytes");
 
 int sort_passes_for(int begin_bit, int end_bit);
+void sort_set_force_wide(bool on);   // test hook: 64-bit look-back status words at any size
 
 hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, const GeomBuf& g, hipStream_t st);
 // The preprocess of several views in one pass over the Gaussians (everything launch_preprocess_fwd

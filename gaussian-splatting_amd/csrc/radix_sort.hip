@@ -10,6 +10,7 @@
 //
 // Traffic per pass: key + 4 B read and written per pair, plus 1 KiB of status
 // words per 4096-pair tile.
+#include <atomic>
 #include <mutex>
 
 #include "kernels.h"
@@ -19,6 +20,18 @@ namespace gs {
 constexpr uint32_t ST_AGG = 1u << 30;   // tile count published
 constexpr uint32_t ST_INCL = 2u << 30;  // inclusive prefix published
 constexpr uint32_t ST_MASK = (1u << 30) - 1;
+// The same three for a status word of type S (u32: counts below 2^30; u64: any count a u32 position can reach).
+template <class S> struct St {
+    static constexpr S AGG = (S)1 << (sizeof(S) * 8 - 2);
+    static constexpr S INCL = (S)2 << (sizeof(S) * 8 - 2);
+    static constexpr S MASK = AGG - 1;
+};
+
+namespace {
+std::atomic<int> g_force_wide{0};
+}
+bool sort_force_wide() { return g_force_wide.load(std::memory_order_relaxed) != 0; }
+void sort_set_force_wide(bool on) { g_force_wide.store(on ? 1 : 0, std::memory_order_relaxed); }
 constexpr uint32_t SPIN_LIMIT = 1u << 22;
 #ifndef GS_LOOK_BATCH
 #define GS_LOOK_BATCH 4
@@ -122,11 +135,11 @@ struct SegArgs {
     int nseg, ntiles;
 };
 
-template <class K, int THREADS, int ITEMS, int BITS, bool SEG>
+template <class K, int THREADS, int ITEMS, int BITS, bool SEG, class S = uint32_t>
 __global__ void __launch_bounds__(THREADS, (GS_OS_BLOCKS * THREADS) / 256)
 onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __restrict__ kout,
                 uint32_t* __restrict__ vout, int64_t n, int shift, int bits, const uint32_t* __restrict__ gbase,
-                uint32_t* status, uint32_t* ticket, uint32_t* err, const SegArgs seg) {
+                S* status, uint32_t* ticket, uint32_t* err, const SegArgs seg) {
     constexpr int NW = THREADS / 64;
     constexpr int TILE = THREADS * ITEMS;
     constexpr bool ONE_PHASE = sizeof(K) == 4;  // keys and values fit the staging area together
@@ -183,9 +196,10 @@ onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* 
     __syncthreads();
     const bool dthread = tid < 256;  // threads that own a digit
     const uint32_t dcount = dthread ? s_hist[tid] : 0u;
-    uint32_t* const my = status + (size_t)tile * 256 + tid;
+    S* const my = status + (size_t)tile * 256 + tid;
     if (dthread)
-        __hip_atomic_store(my, dcount | (first_tile ? ST_INCL : ST_AGG), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(my, (S)dcount | (first_tile ? St<S>::INCL : St<S>::AGG), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     uint32_t tile_total;
     const uint32_t dstart = block_scan_excl_256_nw<NW>(dcount, s_tmp, &tile_total);
     if (dthread) s_dstart[tid] = dstart;
@@ -238,18 +252,18 @@ onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* 
             uint32_t spins = 0;
             bool done = false;
             while (!done) {
-                uint32_t v[LOOK_BATCH];
+                S v[LOOK_BATCH];
 #pragma unroll
                 for (int i = 0; i < LOOK_BATCH; ++i) {
                     const int64_t t = look - i;
                     v[i] = t >= 0 ? __hip_atomic_load(status + (size_t)t * 256 + tid, __ATOMIC_RELAXED,
                                                       __HIP_MEMORY_SCOPE_AGENT)
-                                  : ST_INCL;
+                                  : St<S>::INCL;
                 }
 #pragma unroll
                 for (int i = 0; i < LOOK_BATCH; ++i) {
                     if (done) break;
-                    const uint32_t flag = v[i] & ~ST_MASK;
+                    const S flag = v[i] & ~St<S>::MASK;
                     if (flag == 0) {  // not published yet: poll again from this tile
                         look -= i;
                         if (++spins > SPIN_LIMIT) {
@@ -260,13 +274,14 @@ onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* 
                         }
                         goto next_round;
                     }
-                    excl += v[i] & ST_MASK;
-                    if (flag == ST_INCL) done = true;
+                    excl += (uint32_t)(v[i] & St<S>::MASK);
+                    if (flag == St<S>::INCL) done = true;
                 }
                 look -= LOOK_BATCH;
             next_round:;
             }
-            __hip_atomic_store(my, ((excl + dcount) & ST_MASK) | ST_INCL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(my, ((S)(excl + dcount) & St<S>::MASK) | St<S>::INCL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
         uint32_t base;
         if (SEG) {
@@ -626,6 +641,18 @@ hipError_t radix_sort_impl(K* keys[2], uint32_t* vals[2], int64_t n, int begin_b
     for (int p = 0; p < passes; ++p) {
         int shift, bits;
         digit_of_pass(end_bit - begin_bit, passes, p, &shift, &bits);
+        if (t.wide) {
+            // 2^30 pairs and more: 64-bit look-back words, one kernel per key type (8-bit digit loop)
+            auto kern = onesweep_kernel<K, OS_THREADS, OS_ITEMS, 8, false, uint64_t>;
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)OS_LDS);
+            if (ea != hipSuccess) return ea;
+            hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(OS_THREADS), OS_LDS, st, keys[cur], vals[cur],
+                               keys[cur ^ 1], vals[cur ^ 1], n, begin_bit + shift, bits, t.ghist + p * 256,
+                               (uint64_t*)t.status + (size_t)p * tiles * 256, t.ticket + p, t.err, SegArgs());
+            cur ^= 1;
+            continue;
+        }
         // u32 keys (the rasterizer's two sorts) have kernels for 6-, 7- and 8-bit digits
         auto kern = onesweep_kernel<K, OS_THREADS, OS_ITEMS, 8, false>;
         if (sizeof(K) == 4 && bits <= 6) kern = onesweep_kernel<K, OS_THREADS, OS_ITEMS, sizeof(K) == 4 ? 6 : 8, false>;
@@ -635,7 +662,7 @@ hipError_t radix_sort_impl(K* keys[2], uint32_t* vals[2], int64_t n, int begin_b
         if (ea != hipSuccess) return ea;
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(OS_THREADS), OS_LDS, st, keys[cur], vals[cur],
                            keys[cur ^ 1], vals[cur ^ 1], n, begin_bit + shift, bits, t.ghist + p * 256,
-                           t.status + (size_t)p * tiles * 256, t.ticket + p, t.err, SegArgs());
+                           (uint32_t*)t.status + (size_t)p * tiles * 256, t.ticket + p, t.err, SegArgs());
         cur ^= 1;
     }
     *result_buffer = cur;
@@ -676,6 +703,7 @@ FusedTemp fused_temp_view(void* temp, int64_t R, int n_visible, int nbits) {
 
 bool fused_sort_fits(int64_t R, int n_visible, int nbits) {
     if (R <= 0 || n_visible <= 0 || sort_passes_for(0, nbits) != 2) return false;
+    if (sort_status_wide((size_t)R)) return false;  // its look-back words are 32-bit: the plain passes take over
     int lowshift, lowbits;
     digit_of_pass(nbits, 2, 0, &lowshift, &lowbits);
     const int hb = nbits - lowbits;

@@ -18,7 +18,7 @@ struct RenderFwdArgs {
     const uint2* ranges;
     const uint32_t* point_list;
     const SplatRec* rec;
-    float2* gstat;
+    GStat* gstat;
     const float* bg;
     int W, H, grid_x, ntiles;
     float* final_T;
@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
     __shared__ float4 s_q2[TILE_PIX];  // r, g, b, 1/depth
     __shared__ float4 s_q3[TILE_PIX];  // rep0 .. rep3
     __shared__ float s_gsum[4][TILE_PIX];
-    __shared__ float s_gcnt[4][TILE_PIX];
+    __shared__ uint32_t s_gcnt[4][TILE_PIX];
     __shared__ int s_wdone[4];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -101,7 +101,10 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
 #pragma unroll 1
         for (int j0 = 0; j0 < nb; j0 += 16) {
             if (live == 0) {  // nothing left for this wave: its share of the remaining statistics is zero
-                if (lane < 16) s_gsum[w][j0 + lane] = s_gcnt[w][j0 + lane] = 0.f;
+                if (lane < 16) {
+                    s_gsum[w][j0 + lane] = 0.f;
+                    s_gcnt[w][j0 + lane] = 0u;
+                }
                 continue;
             }
             float tv[16];
@@ -153,7 +156,7 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
             const float tot = rows_sum4(row_transpose_sum16(tv, lane));
             if (lane < 16) {
                 s_gsum[w][j0 + lane] = tot;
-                s_gcnt[w][j0 + lane] = (float)(uint32_t)((((lane & 8) ? cnt_hi : cnt_lo) >> ((lane & 7) * 8)) & 0xffu);
+                s_gcnt[w][j0 + lane] = (uint32_t)((((lane & 8) ? cnt_hi : cnt_lo) >> ((lane & 7) * 8)) & 0xffu);
             }
         }
         if (lane == 0) s_wdone[w] = live == 0 ? 1 : 0;
@@ -163,11 +166,11 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
         for (int h = 0; h < 2; ++h) {
             const int j = (tid >> 1) + 128 * h;
             if (j < nb) {
-                const float c = s_gcnt[0][j] + s_gcnt[1][j] + s_gcnt[2][j] + s_gcnt[3][j];
-                if (c > 0.0f) {
-                    const float s = s_gsum[0][j] + s_gsum[1][j] + s_gsum[2][j] + s_gsum[3][j];
-                    float* dst = reinterpret_cast<float*>(a.gstat + __float_as_uint(s_q1[j].w)) + (tid & 1);
-                    atomicAdd(dst, (tid & 1) ? c : s);
+                const uint32_t c = s_gcnt[0][j] + s_gcnt[1][j] + s_gcnt[2][j] + s_gcnt[3][j];
+                if (c != 0u) {
+                    GStat* dst = a.gstat + __float_as_uint(s_q1[j].w);
+                    if (tid & 1) atomicAdd(&dst->count, c);   // integer, as the reference's int atomicAdd
+                    else atomicAdd(&dst->sum, s_gsum[0][j] + s_gsum[1][j] + s_gsum[2][j] + s_gsum[3][j]);
                 }
             }
         }

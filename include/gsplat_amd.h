@@ -42,7 +42,7 @@ typedef enum {
     GSR_OK = 0,
     GSR_ERR_ARG = -1,        /* null / inconsistent argument */
     GSR_ERR_DIM = -2,        /* unsupported number of `reps` channels (supported: 0, 4) */
-    GSR_ERR_OVERFLOW = -3,   /* number of (Gaussian, tile) instances >= 2^30 */
+    GSR_ERR_OVERFLOW = -3,   /* more than 2^31 - 1 (Gaussian, tile) instances, the reference's limit (its count is an int) */
     GSR_ERR_BUFFER = -4,     /* a caller buffer is smaller than the matching *_bytes query */
     GSR_ERR_HIP = -5,        /* a HIP runtime call failed */
     GSR_ERR_SORT = -6,       /* radix sort look-back did not complete */
@@ -231,7 +231,7 @@ int gsr_backward_geometry_batch_range(const GsrScene* scene, int nviews, const G
  * (gsr_forward_stage1 with preprocessed = 1 is also allowed: it repeats the sums and the copy.)
  * Needs the SH tensors split (scene->shs_rest), M == 16 and scales + rotations; the camera fields,
  * W, H and antialiasing of `scene` are ignored (each view brings its own).  Returns
- * GSR_ERR_OVERFLOW if a view has 2^30 instances or more. */
+ * GSR_ERR_OVERFLOW if a view has more than 2^31 - 1 instances. */
 typedef struct {
     const float* viewmatrix;   /* device [16] */
     const float* projmatrix;   /* device [16] */
@@ -357,6 +357,10 @@ size_t gso_compact_temp_bytes(int64_t N);
 int gso_compact_map(int64_t N, const uint8_t* keep, uint32_t* src_of_dst, void* temp, size_t temp_bytes, int64_t* kept,
                     void* stream);
 int gso_gather_rows(const void* src, void* dst, const uint32_t* src_of_dst, int64_t K, int M, void* stream);
+
+/* Test hook: while on, the radix sorts use the 64-bit look-back status words of sorts of 2^30 pairs and more
+ * at any size (gsr_sort_temp_bytes and gsr_binning_bytes answer accordingly). */
+void gsr_test_force_wide_sort_status(int on);
 
 /* Test hook: while on, every gsr_forward_stage2 sets its sort's error word as a tripped look-back would. */
 void gsr_test_inject_sort_error(int on);

@@ -219,3 +219,18 @@ def test_sort_error_offset_is_inside_the_temp_area():
     from _gsplat_lib import lib
     L = lib()
     assert 0 < L.gsr_sort_temp_error_offset() < L.gsr_sort_temp_bytes(1)
+
+
+def test_rasterizer_with_64_bit_sort_status_words(oracle):
+    """More than 2^30 instances (the reference allows 2^31 - 1, rasterizer_impl.cu:338) take the plain emission
+    and radix passes with 64-bit look-back words instead of the fused emission; the test hook selects that path
+    on a scene the checker can render."""
+    from _gsplat_lib import lib
+    L = lib()
+    sc = synth.tiny_scene(P=300, width=75, height=45, seed=9, scale=0.1)
+    try:
+        L.gsr_test_force_wide_sort_status(1)
+        rs, ten = scene_to_torch(sc, antialiasing=True)
+        _compare(oracle, sc, rs, ten, True, (0, 0, 0))
+    finally:
+        L.gsr_test_force_wide_sort_status(0)

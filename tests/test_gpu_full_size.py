@@ -257,3 +257,37 @@ def test_c5_dist2_20M_points(oracle):
     sel = ref >= 0
     assert sel.sum() >= P // 97
     assert np.array_equal(got[sel], ref[sel])
+
+
+def test_sort_more_than_2_pow_30_pairs():
+    """The stand-alone sort beyond 2^30 pairs (64-bit look-back words; the reference's instance count may
+    reach 2^31 - 1): size-independent properties on the device, no checker at this size.  About 35 GB."""
+    import ctypes as C
+    from _gsplat_lib import lib
+    L = lib()
+    n = (1 << 30) + 4097
+    end_bit = 33
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(9)
+    k0 = torch.randint(0, 1 << 24, (n,), device=dev, generator=g, dtype=torch.int64)      # many ties
+    k0 |= torch.randint(0, 1 << 9, (n,), device=dev, generator=g, dtype=torch.int64) << 24
+    k0 |= 0x5A << 40                                                                        # bits the sort must ignore
+    v0 = torch.arange(n, device=dev, dtype=torch.int32)
+    sum_in = int(k0.sum())
+    k1, v1 = torch.empty_like(k0), torch.empty_like(v0)
+    temp = torch.empty(L.gsr_sort_temp_bytes(n), dtype=torch.uint8, device=dev)
+    res = C.c_int(-1)
+    rc = L.gsr_sort_pairs_u64_u32(k0.data_ptr(), v0.data_ptr(), k1.data_ptr(), v1.data_ptr(), n, end_bit,
+                                  temp.data_ptr(), temp.numel(), torch.cuda.current_stream().cuda_stream, C.byref(res))
+    assert rc == 0
+    torch.cuda.synchronize()
+    off = L.gsr_sort_temp_error_offset()
+    assert int(temp[off:off + 4].view(torch.int32).item()) == 0
+    ko, vo = (k0, v0) if res.value == 0 else (k1, v1)
+    del temp
+    mk = ko & ((1 << end_bit) - 1)
+    assert bool((mk[1:] >= mk[:-1]).all())                                  # sorted on the key bits
+    same = mk[1:] == mk[:-1]
+    assert bool((vo[1:][same] > vo[:-1][same]).all())                       # stable: ties keep input order
+    assert int(ko.sum()) == sum_in and bool(((ko >> 40) == 0x5A).all())     # the same multiset of keys, upper bits kept
+    assert int(vo.long().sum()) == n * (n - 1) // 2                         # a permutation of the values

@@ -180,3 +180,25 @@ def test_fused_losses_match_the_reference_composition():
         l1.backward()
         assert abs(float(l1) - float(fx[f"l1rep_{i}"])) <= 1e-6 * max(1.0, float(fx[f"l1rep_{i}"]))
         assert np.allclose(rep.grad.cpu().numpy(), fx[f"gradrep_{i}"], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("n,end_bit", [(4097, 47), (100_003, 45), (300_000, 64)])
+def test_sort_with_64_bit_status_words(oracle, n, end_bit):
+    """Sorts of 2^30 pairs and more publish their look-back prefixes in 64-bit status words (a 32-bit word has
+    30 bits for the count); the test hook selects them at a size the checker can sort too."""
+    from _gsplat_lib import lib
+    L = lib()
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 2 ** 63, size=n, dtype=np.int64).astype(np.uint64) % np.uint64(30_000)
+    if end_bit == 64:
+        keys = rng.integers(0, 2 ** 63, size=n, dtype=np.int64).astype(np.uint64) * np.uint64(2) + (keys & np.uint64(1))
+    vals = np.arange(n, dtype=np.uint32)
+    small = L.gsr_sort_temp_bytes(n)
+    try:
+        L.gsr_test_force_wide_sort_status(1)
+        assert L.gsr_sort_temp_bytes(n) > small
+        ko, vo = _gpu_sort(keys, vals, end_bit)
+    finally:
+        L.gsr_test_force_wide_sort_status(0)
+    kr, vr = oracle.sort_pairs(keys, vals, end_bit)
+    assert np.array_equal(ko, kr) and np.array_equal(vo, vr)
