@@ -12,6 +12,26 @@ from _gsplat_lib import (GsrBackwardIO, GsrBackwardView, GsrForwardOut, GsrForwa
 
 SUPPORTED_DIMS = (0, 4)
 
+# The compiled PyTorch-ROCm host extension (csrc/torch/ext.cpp): the reference's three pybind functions
+# over the C ABI.  The calls below with the reference's own arguments go through it; the ctypes
+# code in this file serves them only if the extension has not been built, and always serves the
+# arguments the reference does not have (split SH tensors, raw parameters, prepared views, gradient
+# buffers to write into).
+try:
+    from . import _hip_ext
+except ImportError:
+    _hip_ext = None
+
+
+def host_layer():
+    """Which host layer serves the reference-signature calls: 'torch extension' or 'ctypes'."""
+    return "torch extension" if _hip_ext is not None else "ctypes"
+
+
+def _events_address():
+    ev = profile_events()
+    return C.addressof(ev) if ev is not None else 0
+
 
 def _scene(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
            tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, antialiasing, debug, reps, keep,
@@ -65,6 +85,19 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     _check_shapes(means3D, reps)
     if not means3D.is_cuda:
         raise RuntimeError("means3D must be a GPU tensor (there is no CPU path)")
+    if _hip_ext is not None and sh_rest is None and not raw_params and prepared is None:
+        addr, slot = sort_errors.take()
+        try:
+            res = _hip_ext.rasterize_gaussians(
+                background, means3D, colors, opacity, scales, rotations, float(scale_modifier), cov3D_precomp,
+                viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), int(image_height), int(image_width), sh,
+                int(degree), campos, bool(prefiltered), bool(antialiasing), bool(debug),
+                reps if reps is not None else torch.Tensor([]), _events_address(), addr)
+        except Exception:
+            sort_errors.release(slot)
+            raise
+        sort_errors.submitted(slot)
+        return res
     L = lib()
     dev = means3D.device
     P, H, W = means3D.size(0), int(image_height), int(image_width)
@@ -134,6 +167,14 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
     to their contents when `accumulate` is set."""
     L = lib()
     sort_errors.poll()
+    if _hip_ext is not None and sh_rest is None and not raw_params and into is None and not accumulate:
+        e = torch.Tensor([])
+        return _hip_ext.rasterize_gaussians_backward(
+            background, means3D, radii, colors, opacities, scales, rotations, float(scale_modifier), cov3D_precomp,
+            viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), dL_dout_color,
+            dL_dout_invdepth if dL_dout_invdepth is not None else e, dL_dout_reps if dL_dout_reps is not None else e,
+            sh, int(degree), campos, geomBuffer, int(R), binningBuffer, imageBuffer, bool(antialiasing), bool(debug),
+            reps if reps is not None else e, _events_address())
     dev = means3D.device
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -321,6 +362,8 @@ def preprocess_batch(means3D, opacities, scales, rotations, scale_modifier, sh, 
 
 def mark_visible(means3D, viewmatrix, projmatrix):
     """rasterize_points.cu:347-365."""
+    if _hip_ext is not None:
+        return _hip_ext.mark_visible(means3D, viewmatrix, projmatrix)
     L = lib()
     dev = means3D.device
     P = means3D.size(0)

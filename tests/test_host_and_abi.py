@@ -151,3 +151,19 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(d, f), errors="ignore").read()
                 assert "gs_oracle" not in txt and "oracle/" not in txt, os.path.join(d, f)
+
+
+def test_compiled_host_extension_is_the_host_layer():
+    """The PyTorch-ROCm C++ extension (csrc/torch/ext.cpp) exports the reference's three pybind functions
+    (submodules/diff-gaussian-rasterization/ext.cpp:15-19) and is what serves the reference-signature calls."""
+    from diff_gaussian_rasterization import _C
+    assert _C.host_layer() == "torch extension"
+    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible"):
+        assert callable(getattr(_C._hip_ext, name))
+    import torch
+    assert _C._hip_ext.mark_visible(torch.zeros(0, 3), torch.eye(4), torch.eye(4)).numel() == 0   # P == 0: no GPU needed
+    e = torch.Tensor([])
+    with pytest.raises(RuntimeError, match="means3D must have dimensions"):
+        _C._hip_ext.rasterize_gaussians(torch.zeros(3), torch.zeros(5, 2), e, torch.zeros(5, 1), torch.zeros(5, 3),
+                                        torch.zeros(5, 4), 1.0, e, torch.eye(4), torch.eye(4), 1.0, 1.0, 16, 16,
+                                        torch.zeros(5, 16, 3), 3, torch.zeros(3), False, False, False, torch.zeros(5, 4))
