@@ -54,14 +54,6 @@ struct PreBwdArgs {
     float* dL_dreps;
 };
 
-enum ShMode { SH_NONE = 0, SH_DIRECT = 1, SH_CAT16 = 2, SH_SPLIT16 = 3 };
-
-
-template <int MODE>
-struct ShLds {
-    static constexpr int bytes_per_wave =
-        MODE == SH_CAT16 ? SH_WAVE_LDS_F4 * 16 : (MODE == SH_SPLIT16 ? REST_WAVE_F * 4 : 0);
-};
 
 // Everything for one rendered Gaussian.
 template <int MODE>

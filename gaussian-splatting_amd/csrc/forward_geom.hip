@@ -37,18 +37,31 @@ struct PreArgs {
     uint32_t* vis_sums;
 };
 
+// MODE: how the SH rows are read (ShMode).  With 16 coefficients a wave first projects its 64 Gaussians,
+// then moves the rows of those that are on screen from global memory into LDS as 16-byte chunks in
+// address order (a lane walking its own 192-byte row issues 48 strided dword loads and drags whole
+// lines of culled neighbours along), and every lane evaluates its colour from its row in LDS.
+template <int MODE>
 __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs a) {
+    constexpr int WAVE_LDS = ShLds<MODE>::bytes_per_wave;
+    __shared__ __align__(16) char s_sh[WAVE_LDS ? 4 * WAVE_LDS : 16];
     __shared__ uint32_t s_tmp[8];
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wave_g0 = blockIdx.x * PRE_BLOCK + w * 64;
+    const int nrows = min(64, a.P - wave_g0);  // <= 0 for waves past the end
+    float* lds = reinterpret_cast<float*>(s_sh + w * WAVE_LDS);
     uint32_t tiles = 0;
-    if (idx < a.P) {
-        const Cam c = load_cam(a.cam, a.W, a.H, a.tanx, a.tany, a.mod, a.D, a.M, a.aa);
-        int radius = 0;
-        uint4 bin = make_uint4(0, 0, 0, 0);
-        const V3 p = v3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+    const bool live = idx < a.P;
+    const Cam c = load_cam(a.cam, a.W, a.H, a.tanx, a.tany, a.mod, a.D, a.M, a.aa);
+    bool vis = false;
+    Splat sp;
+    V3 p = v3(0, 0, 0);
+    float cov6[6];
+    if (live) {
+        p = v3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
         float depth;
         if (!near_cull(p, c.view, &depth)) {
-            float cov6[6];
             if (a.cov3D_precomp) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) cov6[i] = a.cov3D_precomp[6 * (size_t)idx + i];
@@ -65,11 +78,46 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs
             }
             float opac = a.opacities[idx];
             if (a.raw) opac = act_sigmoid(opac);
-            Splat sp;
-            if (project_splat(c, p, cov6, opac, depth, &sp)) {
-                V3 col;
-                if (a.colors_precomp) {
-                    col = v3(a.colors_precomp[3 * idx], a.colors_precomp[3 * idx + 1], a.colors_precomp[3 * idx + 2]);
+            vis = project_splat(c, p, cov6, opac, depth, &sp);
+        }
+    }
+    if (MODE == SH_CAT16 || MODE == SH_SPLIT16) {
+        const uint64_t rows = __ballot(vis);
+        if (rows && nrows > 0) {
+            if (MODE == SH_CAT16)
+                sh_rows_load(a.shs + (size_t)wave_g0 * SH_ROW_F, reinterpret_cast<float4*>(lds), rows, nrows, lane);
+            else
+                rest_rows_copy<0>(const_cast<float*>(a.shs_rest) + (size_t)wave_g0 * REST_ROW_F, lds, rows, nrows, lane);
+        }
+        wave_lds_sync();
+    }
+    if (live) {
+        int radius = 0;
+        uint4 bin = make_uint4(0, 0, 0, 0);
+        if (vis) {
+            const V3 campos = v3(c.campos[0], c.campos[1], c.campos[2]);
+            V3 col;
+            if (MODE == SH_NONE) {
+                col = v3(a.colors_precomp[3 * idx], a.colors_precomp[3 * idx + 1], a.colors_precomp[3 * idx + 2]);
+            } else {
+                if (MODE == SH_CAT16) {
+                    float shv[SH_ROW_F];
+                    sh_row_get(reinterpret_cast<const float4*>(lds), lane, shv);
+                    const ShRegs sh = {shv};
+                    col = sh_to_rgb(c.sh_degree, p, campos, sh);
+                } else if (MODE == SH_SPLIT16) {
+                    // coefficient 0 from global memory, the others from the lane's row in LDS (row stride 45
+                    // dwords: odd, no bank conflicts)
+                    struct ShRow {
+                        float dc0, dc1, dc2;
+                        const float* row;
+                        __device__ __forceinline__ V3 operator()(int k) const {
+                            return k == 0 ? v3(dc0, dc1, dc2) : v3(row[3 * k - 3], row[3 * k - 2], row[3 * k - 1]);
+                        }
+                    };
+                    const ShRow sh = {a.shs[3 * (size_t)idx], a.shs[3 * (size_t)idx + 1], a.shs[3 * (size_t)idx + 2],
+                                      lds + lane * REST_ROW_F};
+                    col = sh_to_rgb(c.sh_degree, p, campos, sh);
                 } else {
                     ShPtr sh;
                     if (a.shs_rest) {
@@ -79,29 +127,29 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs
                         sh.dc = a.shs + (size_t)idx * a.M * 3;
                         sh.rest = sh.dc + 3;
                     }
-                    col = sh_to_rgb(c.sh_degree, p, v3(c.campos[0], c.campos[1], c.campos[2]), sh);
-                    a.clamped[idx] = (uint8_t)((col.x < 0 ? 1 : 0) | (col.y < 0 ? 2 : 0) | (col.z < 0 ? 4 : 0));
-                    col = v3(fmax_(col.x, 0.0f), fmax_(col.y, 0.0f), fmax_(col.z, 0.0f));
+                    col = sh_to_rgb(c.sh_degree, p, campos, sh);
                 }
-                float4 rp = make_float4(0, 0, 0, 0);
-                if (a.DIM == 4) rp = reinterpret_cast<const float4*>(a.reps)[idx];
-                float4* r4 = reinterpret_cast<float4*>(a.rec + idx);
-                r4[0] = make_float4(sp.xy.x, sp.xy.y, sp.conic_opacity.x, sp.conic_opacity.y);
-                r4[1] = make_float4(sp.conic_opacity.z, sp.conic_opacity.w, col.x, col.y);
-                r4[2] = make_float4(col.z, 1 / sp.depth, rp.x, rp.y);
-                r4[3] = make_float4(rp.z, rp.w, sp.depth, 0.0f);
-                if (!a.cov3D_precomp) {
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) a.cov3D[6 * (size_t)idx + i] = cov6[i];
-                }
-                a.out_depths[idx] = sp.depth;
-                radius = sp.radius;
-                tiles = sp.tiles;
-                bin.x = (uint32_t)sp.rect.x0 | ((uint32_t)sp.rect.y0 << 16);
-                bin.y = (uint32_t)(sp.rect.x1 - sp.rect.x0) | ((uint32_t)(sp.rect.y1 - sp.rect.y0) << 16);
-                bin.z = f2bits(sp.depth);
-                bin.w = tiles;
+                a.clamped[idx] = (uint8_t)((col.x < 0 ? 1 : 0) | (col.y < 0 ? 2 : 0) | (col.z < 0 ? 4 : 0));
+                col = v3(fmax_(col.x, 0.0f), fmax_(col.y, 0.0f), fmax_(col.z, 0.0f));
             }
+            float4 rp = make_float4(0, 0, 0, 0);
+            if (a.DIM == 4) rp = reinterpret_cast<const float4*>(a.reps)[idx];
+            float4* r4 = reinterpret_cast<float4*>(a.rec + idx);
+            r4[0] = make_float4(sp.xy.x, sp.xy.y, sp.conic_opacity.x, sp.conic_opacity.y);
+            r4[1] = make_float4(sp.conic_opacity.z, sp.conic_opacity.w, col.x, col.y);
+            r4[2] = make_float4(col.z, 1 / sp.depth, rp.x, rp.y);
+            r4[3] = make_float4(rp.z, rp.w, sp.depth, 0.0f);
+            if (!a.cov3D_precomp) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) a.cov3D[6 * (size_t)idx + i] = cov6[i];
+            }
+            a.out_depths[idx] = sp.depth;
+            radius = sp.radius;
+            tiles = sp.tiles;
+            bin.x = (uint32_t)sp.rect.x0 | ((uint32_t)sp.rect.y0 << 16);
+            bin.y = (uint32_t)(sp.rect.x1 - sp.rect.x0) | ((uint32_t)(sp.rect.y1 - sp.rect.y0) << 16);
+            bin.z = f2bits(sp.depth);
+            bin.w = tiles;
         }
         a.radii[idx] = radius;
         a.bin[idx] = bin;
@@ -690,7 +738,11 @@ hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, cons
     a.block_sums = g.block_sums;
     a.vis_sums = g.vis_sums;
     const int nb = (s.P + PRE_BLOCK - 1) / PRE_BLOCK;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, a);
+    const dim3 grid(nb), block(PRE_BLOCK);
+    if (!s.shs) hipLaunchKernelGGL(preprocess_fwd_kernel<SH_NONE>, grid, block, 0, st, a);
+    else if (s.M == 16 && s.shs_rest) hipLaunchKernelGGL(preprocess_fwd_kernel<SH_SPLIT16>, grid, block, 0, st, a);
+    else if (s.M == 16) hipLaunchKernelGGL(preprocess_fwd_kernel<SH_CAT16>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(preprocess_fwd_kernel<SH_DIRECT>, grid, block, 0, st, a);
     return hipGetLastError();
 }
 

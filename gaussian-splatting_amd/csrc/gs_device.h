@@ -289,6 +289,17 @@ __device__ __forceinline__ void rest_rows_copy(float* __restrict__ g, float* lds
     }
 }
 
+// How a per-Gaussian kernel gets at the SH rows: none (precomputed colours), each lane walking its own
+// row in global memory (any row size), or the wave's 64 rows staged through LDS in 16-byte chunks
+// (16 coefficients; one [P,16,3] tensor, or [P,1,3] + [P,15,3]).
+enum ShMode { SH_NONE = 0, SH_DIRECT = 1, SH_CAT16 = 2, SH_SPLIT16 = 3 };
+
+template <int MODE>
+struct ShLds {
+    static constexpr int bytes_per_wave =
+        MODE == SH_CAT16 ? SH_WAVE_LDS_F4 * 16 : (MODE == SH_SPLIT16 ? REST_WAVE_F * 4 : 0);
+};
+
 // One lane's row between LDS and registers.
 __device__ __forceinline__ void sh_row_get(const float4* lds, int lane, float (&v)[SH_ROW_F]) {
 #pragma unroll
