@@ -146,15 +146,14 @@ GS_HD V3 xform_vec_4x3_T(V3 p, const float* m) {
               m[8] * p.x + m[9] * p.y + m[10] * p.z);
 }
 
-// auxiliary.h:119-129
-GS_HD V3 dnormvdv(V3 v, V3 dv) {
-    const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
-    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-    V3 r;
-    r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
-    r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
-    r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
-    return r;
+// Backward of d = v / |v|: the Jacobian is (I - d d^T) / |v|, so the gradient with respect to v is the part
+// of the incoming gradient that is orthogonal to d, over |v|.  (The reference's dnormvdv,
+// auxiliary.h:119-129, expands the same product per component.)
+GS_HD V3 unit_vector_bwd(V3 v, V3 g_unit) {
+    const float len = sqrtf(dot(v, v));
+    const V3 d = v3(v.x / len, v.y / len, v.z / len);
+    const float along = dot(d, g_unit);
+    return v3((g_unit.x - along * d.x) / len, (g_unit.y - along * d.y) / len, (g_unit.z - along * d.z) / len);
 }
 
 // auxiliary.h:40-43 -- evaluated in double, rounded once.
@@ -243,89 +242,64 @@ GS_HD V3 sh_to_rgb(int deg, V3 pos, V3 campos, SH sh) {
     return res;
 }
 
-// backward.cu:23-142.  g = dL/dRGB with clamped channels already zeroed.
-// OUT is any callable (k, V3) that stores dL/dsh[k].  Returns the part of
-// dL/dmean that flows through the view direction.
+// Backward of sh_to_rgb (what backward.cu:23-142 computes), written from the structure of the forward:
+// colour = 0.5 + sum_k B_k(d) sh_k with d the unit view direction, so
+//     dL/dsh_k = B_k(d) * g                       (g = dL/dRGB, clamped channels already zeroed)
+//     dL/dd    = sum_k (sh_k . g) * grad B_k(d)
+// and dL/dposition follows through d = (pos - campos) / |pos - campos|.  The coefficients are
+// projected on g first (one scalar per coefficient), so the direction gradient is a sum of scalars
+// times the polynomial gradients below instead of three-vectors.  OUT is any callable (k, V3) that
+// stores dL/dsh[k].  Returns the part of dL/dmean that flows through the view direction.
 template <class SH, class OUT>
 GS_HD V3 sh_to_rgb_bwd(int deg, V3 pos, V3 campos, V3 g, SH sh, OUT out) {
-    const V3 dir_orig = sub(pos, campos);
-    const float len = sqrtf(dot(dir_orig, dir_orig));
-    const V3 dir = v3(dir_orig.x / len, dir_orig.y / len, dir_orig.z / len);
-    const float x = dir.x, y = dir.y, z = dir.z;
-
-    V3 dx = v3(0, 0, 0), dy = v3(0, 0, 0), dz = v3(0, 0, 0);
+    const V3 to_point = sub(pos, campos);
+    const float len = sqrtf(dot(to_point, to_point));
+    const float x = to_point.x / len, y = to_point.y / len, z = to_point.z / len;
+    V3 gd = v3(0, 0, 0);   // dL/dd
     out(0, scale(GS_SH_C0, g));
     if (deg > 0) {
         out(1, scale(-GS_SH_C1 * y, g));
         out(2, scale(GS_SH_C1 * z, g));
         out(3, scale(-GS_SH_C1 * x, g));
-        dx = scale(-GS_SH_C1, sh(3));
-        dy = scale(-GS_SH_C1, sh(1));
-        dz = scale(GS_SH_C1, sh(2));
-        if (deg > 1) {
-            const float xx = x * x, yy = y * y, zz = z * z;
-            const float xy = x * y, yz = y * z, xz = x * z;
-            out(4, scale(GS_SH_C2_0 * xy, g));
-            out(5, scale(GS_SH_C2_1 * yz, g));
-            out(6, scale(GS_SH_C2_2 * (2.f * zz - xx - yy), g));
-            out(7, scale(GS_SH_C2_3 * xz, g));
-            out(8, scale(GS_SH_C2_4 * (xx - yy), g));
-            {
-                V3 t = scale(GS_SH_C2_0 * y, sh(4));
-                t = axpy(t, GS_SH_C2_2 * 2.f * -x, sh(6));
-                t = axpy(t, GS_SH_C2_3 * z, sh(7));
-                t = axpy(t, GS_SH_C2_4 * 2.f * x, sh(8));
-                dx = add(dx, t);
-                t = scale(GS_SH_C2_0 * x, sh(4));
-                t = axpy(t, GS_SH_C2_1 * z, sh(5));
-                t = axpy(t, GS_SH_C2_2 * 2.f * -y, sh(6));
-                t = axpy(t, GS_SH_C2_4 * 2.f * -y, sh(8));
-                dy = add(dy, t);
-                t = scale(GS_SH_C2_1 * y, sh(5));
-                t = axpy(t, GS_SH_C2_2 * 2.f * 2.f * z, sh(6));
-                t = axpy(t, GS_SH_C2_3 * x, sh(7));
-                dz = add(dz, t);
-            }
-            if (deg > 2) {
-                out(9, scale(GS_SH_C3_0 * y * (3.f * xx - yy), g));
-                out(10, scale(GS_SH_C3_1 * xy * z, g));
-                out(11, scale(GS_SH_C3_2 * y * (4.f * zz - xx - yy), g));
-                out(12, scale(GS_SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy), g));
-                out(13, scale(GS_SH_C3_4 * x * (4.f * zz - xx - yy), g));
-                out(14, scale(GS_SH_C3_5 * z * (xx - yy), g));
-                out(15, scale(GS_SH_C3_6 * x * (xx - 3.f * yy), g));
-                // "C * sh[k] * a * b" is evaluated left to right: ((C*sh)*a)*b.
-                auto s2 = [](float c, V3 s, float a) { return v3(c * s.x * a, c * s.y * a, c * s.z * a); };
-                auto s3 = [](float c, V3 s, float a, float b) {
-                    return v3(c * s.x * a * b, c * s.y * a * b, c * s.z * a * b);
-                };
-                V3 t = s3(GS_SH_C3_0, sh(9), 3.f * 2.f, xy);
-                t = add(t, s2(GS_SH_C3_1, sh(10), yz));
-                t = add(t, s3(GS_SH_C3_2, sh(11), -2.f, xy));
-                t = add(t, s3(GS_SH_C3_3, sh(12), -3.f * 2.f, xz));
-                t = add(t, s2(GS_SH_C3_4, sh(13), (-3.f * xx + 4.f * zz - yy)));
-                t = add(t, s3(GS_SH_C3_5, sh(14), 2.f, xz));
-                t = add(t, s3(GS_SH_C3_6, sh(15), 3.f, (xx - yy)));
-                dx = add(dx, t);
-                t = s3(GS_SH_C3_0, sh(9), 3.f, (xx - yy));
-                t = add(t, s2(GS_SH_C3_1, sh(10), xz));
-                t = add(t, s2(GS_SH_C3_2, sh(11), (-3.f * yy + 4.f * zz - xx)));
-                t = add(t, s3(GS_SH_C3_3, sh(12), -3.f * 2.f, yz));
-                t = add(t, s3(GS_SH_C3_4, sh(13), -2.f, xy));
-                t = add(t, s3(GS_SH_C3_5, sh(14), -2.f, yz));
-                t = add(t, s3(GS_SH_C3_6, sh(15), -3.f * 2.f, xy));
-                dy = add(dy, t);
-                t = s2(GS_SH_C3_1, sh(10), xy);
-                t = add(t, s3(GS_SH_C3_2, sh(11), 4.f * 2.f, yz));
-                t = add(t, s3(GS_SH_C3_3, sh(12), 3.f, (2.f * zz - xx - yy)));
-                t = add(t, s3(GS_SH_C3_4, sh(13), 4.f * 2.f, xz));
-                t = add(t, s2(GS_SH_C3_5, sh(14), (xx - yy)));
-                dz = add(dz, t);
-            }
+        const float s1 = dot(sh(1), g), s2 = dot(sh(2), g), s3 = dot(sh(3), g);
+        gd = v3(-GS_SH_C1 * s3, -GS_SH_C1 * s1, GS_SH_C1 * s2);
+    }
+    if (deg > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z;
+        const float xy = x * y, yz = y * z, xz = x * z;
+        out(4, scale(GS_SH_C2_0 * xy, g));
+        out(5, scale(GS_SH_C2_1 * yz, g));
+        out(6, scale(GS_SH_C2_2 * (2.f * zz - xx - yy), g));
+        out(7, scale(GS_SH_C2_3 * xz, g));
+        out(8, scale(GS_SH_C2_4 * (xx - yy), g));
+        const float s4 = GS_SH_C2_0 * dot(sh(4), g), s5 = GS_SH_C2_1 * dot(sh(5), g), s6 = GS_SH_C2_2 * dot(sh(6), g),
+                    s7 = GS_SH_C2_3 * dot(sh(7), g), s8 = GS_SH_C2_4 * dot(sh(8), g);
+        // B4 = xy, B5 = yz, B6 = 2zz - xx - yy, B7 = xz, B8 = xx - yy (times their constants)
+        gd.x += s4 * y - 2.f * s6 * x + s7 * z + 2.f * s8 * x;
+        gd.y += s4 * x + s5 * z - 2.f * s6 * y - 2.f * s8 * y;
+        gd.z += s5 * y + 4.f * s6 * z + s7 * x;
+        if (deg > 2) {
+            out(9, scale(GS_SH_C3_0 * y * (3.f * xx - yy), g));
+            out(10, scale(GS_SH_C3_1 * xy * z, g));
+            out(11, scale(GS_SH_C3_2 * y * (4.f * zz - xx - yy), g));
+            out(12, scale(GS_SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy), g));
+            out(13, scale(GS_SH_C3_4 * x * (4.f * zz - xx - yy), g));
+            out(14, scale(GS_SH_C3_5 * z * (xx - yy), g));
+            out(15, scale(GS_SH_C3_6 * x * (xx - 3.f * yy), g));
+            const float s9 = GS_SH_C3_0 * dot(sh(9), g), s10 = GS_SH_C3_1 * dot(sh(10), g),
+                        s11 = GS_SH_C3_2 * dot(sh(11), g), s12 = GS_SH_C3_3 * dot(sh(12), g),
+                        s13 = GS_SH_C3_4 * dot(sh(13), g), s14 = GS_SH_C3_5 * dot(sh(14), g),
+                        s15 = GS_SH_C3_6 * dot(sh(15), g);
+            // B9 = y(3xx - yy), B10 = xyz, B11 = y(4zz - xx - yy), B12 = z(2zz - 3xx - 3yy),
+            // B13 = x(4zz - xx - yy), B14 = z(xx - yy), B15 = x(xx - 3yy)
+            gd.x += 6.f * s9 * xy + s10 * yz - 2.f * s11 * xy - 6.f * s12 * xz + s13 * (4.f * zz - 3.f * xx - yy) +
+                    2.f * s14 * xz + 3.f * s15 * (xx - yy);
+            gd.y += 3.f * s9 * (xx - yy) + s10 * xz + s11 * (4.f * zz - xx - 3.f * yy) - 6.f * s12 * yz -
+                    2.f * s13 * xy - 2.f * s14 * yz - 6.f * s15 * xy;
+            gd.z += s10 * xy + 8.f * s11 * yz + 3.f * s12 * (2.f * zz - xx - yy) + 8.f * s13 * xz + s14 * (xx - yy);
         }
     }
-    const V3 ddir = v3(dot(dx, g), dot(dy, g), dot(dz, g));
-    return dnormvdv(dir_orig, ddir);
+    return unit_vector_bwd(to_point, gd);
 }
 
 // SH coefficient k of one Gaussian when the DC term and the other
@@ -413,29 +387,46 @@ GS_HD void cov3d_from_scale_rot(V3 s, float mod, V4 q, float* cov6) {
     cov6[3] = Sigma.c[1][1]; cov6[4] = Sigma.c[1][2]; cov6[5] = Sigma.c[2][2];
 }
 
-// backward.cu:333-396
+// Backward of cov3d_from_scale_rot (what backward.cu:333-396 computes).  Read as mathematical matrices
+// (element (row i, column k) is stored at c[k][i]), M = S R with S = diag(mod * scale) scales ROW i of R by
+// s_i, and Sigma = M^T M.  The six stored entries g6 are gradients of the UNIQUE entries, so the full
+// symmetric gradient G has the off-diagonals halved, and
+//     dL/dM = 2 M G,      dL/ds_i = sum_k dL/dM(i,k) R(i,k),      dL/dR(i,k) = s_i dL/dM(i,k).
+// The quaternion gradient is the Frobenius product of dL/dR with the partial derivatives of quat_to_R with
+// respect to (r, x, y, z) -- of the quaternion as given: it is not normalised here.
+GS_HD float m3_frobenius(const M3& a, const M3& b) {
+    float acc = 0.f;
+    for (int c = 0; c < 3; ++c)
+        for (int w = 0; w < 3; ++w) acc += a.c[c][w] * b.c[c][w];
+    return acc;
+}
+
 GS_HD void cov3d_from_scale_rot_bwd(V3 sc, float mod, V4 q, const float* g6, V3* dscale, V4* drot) {
     const float r = q.x, x = q.y, y = q.z, z = q.w;
     const M3 R = quat_to_R(q);
-    M3 S = m3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1);
-    const V3 s = v3(mod * sc.x, mod * sc.y, mod * sc.z);
-    S.c[0][0] = s.x; S.c[1][1] = s.y; S.c[2][2] = s.z;
+    const float s[3] = {mod * sc.x, mod * sc.y, mod * sc.z};
+    M3 S = m3_cols(s[0], 0, 0, 0, s[1], 0, 0, 0, s[2]);
     const M3 M = m3_mul(S, R);
-    const M3 dSigma = m3_cols(g6[0], 0.5f * g6[1], 0.5f * g6[2],
-                              0.5f * g6[1], g6[3], 0.5f * g6[4],
-                              0.5f * g6[2], 0.5f * g6[4], g6[5]);
-    const M3 dM = m3_mul(m3_scale(2.0f, M), dSigma);
-    const M3 Rt = m3_T(R);
-    M3 dMt = m3_T(dM);
-    dscale->x = Rt.c[0][0] * dMt.c[0][0] + Rt.c[0][1] * dMt.c[0][1] + Rt.c[0][2] * dMt.c[0][2];
-    dscale->y = Rt.c[1][0] * dMt.c[1][0] + Rt.c[1][1] * dMt.c[1][1] + Rt.c[1][2] * dMt.c[1][2];
-    dscale->z = Rt.c[2][0] * dMt.c[2][0] + Rt.c[2][1] * dMt.c[2][1] + Rt.c[2][2] * dMt.c[2][2];
-    for (int k = 0; k < 3; ++k) { dMt.c[0][k] *= s.x; dMt.c[1][k] *= s.y; dMt.c[2][k] *= s.z; }
-    const float (*d)[3] = dMt.c;
-    drot->x = 2 * z * (d[0][1] - d[1][0]) + 2 * y * (d[2][0] - d[0][2]) + 2 * x * (d[1][2] - d[2][1]);
-    drot->y = 2 * y * (d[1][0] + d[0][1]) + 2 * z * (d[2][0] + d[0][2]) + 2 * r * (d[1][2] - d[2][1]) - 4 * x * (d[2][2] + d[1][1]);
-    drot->z = 2 * x * (d[1][0] + d[0][1]) + 2 * r * (d[2][0] - d[0][2]) + 2 * z * (d[1][2] + d[2][1]) - 4 * y * (d[2][2] + d[0][0]);
-    drot->w = 2 * r * (d[0][1] - d[1][0]) + 2 * x * (d[2][0] + d[0][2]) + 2 * y * (d[1][2] + d[2][1]) - 4 * z * (d[1][1] + d[0][0]);
+    const M3 G = m3_cols(g6[0], 0.5f * g6[1], 0.5f * g6[2],
+                         0.5f * g6[1], g6[3], 0.5f * g6[4],
+                         0.5f * g6[2], 0.5f * g6[4], g6[5]);
+    const M3 dM = m3_mul(m3_scale(2.0f, M), G);   // stored like R: dM.c[k][i] pairs with R.c[k][i]
+    float ds[3];
+    M3 dR;
+    for (int i = 0; i < 3; ++i) {
+        ds[i] = R.c[0][i] * dM.c[0][i] + R.c[1][i] * dM.c[1][i] + R.c[2][i] * dM.c[2][i];
+        for (int k = 0; k < 3; ++k) dR.c[k][i] = s[i] * dM.c[k][i];
+    }
+    *dscale = v3(ds[0], ds[1], ds[2]);   // with respect to mod * scale, as the reference returns it (backward.cu:377-380)
+    // partial derivatives of quat_to_R, entry by entry in m3_cols order
+    const M3 dR_dr = m3_cols(0, -2 * z, 2 * y, 2 * z, 0, -2 * x, -2 * y, 2 * x, 0);
+    const M3 dR_dx = m3_cols(0, 2 * y, 2 * z, 2 * y, -4 * x, -2 * r, 2 * z, 2 * r, -4 * x);
+    const M3 dR_dy = m3_cols(-4 * y, 2 * x, 2 * r, 2 * x, 0, 2 * z, -2 * r, 2 * z, -4 * y);
+    const M3 dR_dz = m3_cols(-4 * z, -2 * r, 2 * x, 2 * r, -4 * z, 2 * y, 2 * x, 2 * y, 0);
+    drot->x = m3_frobenius(dR, dR_dr);
+    drot->y = m3_frobenius(dR, dR_dx);
+    drot->z = m3_frobenius(dR, dR_dy);
+    drot->w = m3_frobenius(dR, dR_dz);
 }
 
 // The view-dependent pieces of the EWA projection that forward and backward
@@ -570,93 +561,97 @@ GS_HD float splat_power(V2 xy, float px, float py, V4 co, float* dx, float* dy) 
 
 // ---------------------------------------------------------------- backward preprocess
 
-// backward.cu:147-329, one Gaussian.  dconic = (dL/dconic.x, .y, .w).
-// dopacity is read and, under antialiasing, rewritten.  Returns dL/dmean (the
-// covariance path) and fills dcov6.
-GS_HD V3 cov2d_bwd(const Cam& c, V3 mean, const float* cov6, float opacity, V3 dconic,
+// Partial derivatives of the antialiasing ratio f = (x y - z^2) / ((x + w)(y + w) - z^2) with respect to the
+// covariance entries x = c_xx, y = c_yy, z = c_xy, times `scale`: with N the numerator and D the denominator,
+// df/dx = (y D - N (y + w)) / D^2 = w (w y + y^2 + z^2) / D^2, symmetrically for y, and
+// df/dz = -2 z (D - N) / D^2 = -2 w z (w + x + y) / D^2.
+GS_HD V3 aa_ratio_grad(float x, float y, float z, float w, float scale_by) {
+    const float D = w * w + w * (x + y) + x * y - z * z;
+    const float k = scale_by / (D * D);
+    return v3(w * (w * y + y * y + z * z) * k, -2.f * w * z * (w + x + y) * k, w * (w * x + x * x + z * z) * k);
+}
+
+// Backward of the EWA projection for one Gaussian (what backward.cu:147-329 computes).
+// g_conic = gradients of the inverse 2D covariance K = (conic.x, conic.y; conic.y, conic.w), the off-diagonal
+// one PER ENTRY (the blend backward accumulates it with the factor 0.5, backward.cu:682).  dopacity is read
+// and, under antialiasing, rewritten.  Returns dL/dmean through the covariance (and the inverse depth) and
+// fills dcov6, the gradients of the six stored entries of the 3D covariance.
+//
+// Derivation.  The 2D covariance is C = (a'Va, a'Vb; a'Vb, b'Vb) + 0.3 I, with V the 3D covariance and a, b the
+// first two columns of T = W J (GLM product; a = J00 w0 + J02 w2, b = J11 w1 + J12 w2 with w_k the columns of W
+// as stored).  K = C^-1 gives dL/dC = -K G K per entry, G = (gx, gy; gy, gw); the pair parameter c_xy takes twice
+// the off-diagonal entry.  The determinant is regularised as the reference does: 1 / (det^2 + 1e-7).
+GS_HD V3 cov2d_bwd(const Cam& c, V3 mean, const float* cov6, float opacity, V3 g_conic,
                    float* dopacity, const float* dinvdepth, float* dcov6) {
-    const float h_x = c.focal_x, h_y = c.focal_y;
-    const Ewa e = ewa_project(mean, h_x, h_y, c.tanfovx, c.tanfovy, cov6, c.view);
+    const float fx = c.focal_x, fy = c.focal_y;
+    const Ewa e = ewa_project(mean, fx, fy, c.tanfovx, c.tanfovy, cov6, c.view);
+    const float blur = 0.3f;
+    const float A = e.cxx + blur, B = e.cxy, Cc = e.cyy + blur;   // the dilated covariance
+    // gradient with respect to (c_xx, c_xy as a pair, c_yy)
+    float g_xx = 0.f, g_xy = 0.f, g_yy = 0.f;
+    if (c.antialiasing) {
+        // opacity' = opacity * sqrt(max(2.5e-5, ratio)): the factor scales dL/dopacity, and its own gradient goes
+        // into the covariance.  The reference evaluates the ratio's partials at the DILATED entries
+        // (backward.cu:234-249); so does this.
+        const float ratio = (e.cxx * e.cyy - B * B) / (A * Cc - B * B);
+        const float factor = sqrtf(fmax_(0.000025f, ratio));
+        const float g_factor = *dopacity * opacity;
+        *dopacity = *dopacity * factor;
+        const float g_ratio = ratio <= 0.000025f ? 0.f : g_factor / (2 * factor);
+        const V3 d = aa_ratio_grad(A, Cc, B, blur, g_ratio);
+        g_xx = d.x;
+        g_xy = d.y;
+        g_yy = d.z;
+    }
+    const float det = A * Cc - B * B;
+    const float inv2 = 1.0f / ((det * det) + 0.0000001f);
+    if (inv2 != 0) {
+        // -adj G adj / det^2 with adj = (Cc, -B; -B, A)
+        const float gx = g_conic.x, gy = g_conic.y, gw = g_conic.z;
+        const float u0 = Cc * gx - B * gy, u1 = Cc * gy - B * gw;    // first row of adj G
+        const float v0 = A * gy - B * gx, v1 = A * gw - B * gy;      // second row of adj G
+        g_xx += -inv2 * (u0 * Cc - u1 * B);
+        g_yy += -inv2 * (v1 * A - v0 * B);
+        g_xy += -2.f * inv2 * (u1 * A - u0 * B);
+    }
+    const V3 a = v3(e.T.c[0][0], e.T.c[0][1], e.T.c[0][2]);
+    const V3 b = v3(e.T.c[1][0], e.T.c[1][1], e.T.c[1][2]);
+    if (inv2 != 0) {
+        // dL/dV_kl = g_xx a_k a_l + g_xy a_k b_l + g_yy b_k b_l; a stored off-diagonal entry stands for both (k,l) and (l,k)
+        const float av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
+        const int slot[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+        for (int i = 0; i < 6; ++i) dcov6[i] = 0.f;
+        for (int k = 0; k < 3; ++k)
+            for (int l = 0; l < 3; ++l)
+                dcov6[slot[k][l]] += g_xx * av[k] * av[l] + g_xy * av[k] * bv[l] + g_yy * bv[k] * bv[l];
+    } else {
+        for (int i = 0; i < 6; ++i) dcov6[i] = 0.f;
+    }
+    // dL/da = 2 g_xx V a + g_xy V b,  dL/db = 2 g_yy V b + g_xy V a
+    const float (*V)[3] = e.Vrk.c;
+    const V3 Va = v3(V[0][0] * a.x + V[0][1] * a.y + V[0][2] * a.z, V[1][0] * a.x + V[1][1] * a.y + V[1][2] * a.z,
+                     V[2][0] * a.x + V[2][1] * a.y + V[2][2] * a.z);
+    const V3 Vb = v3(V[0][0] * b.x + V[0][1] * b.y + V[0][2] * b.z, V[1][0] * b.x + V[1][1] * b.y + V[1][2] * b.z,
+                     V[2][0] * b.x + V[2][1] * b.y + V[2][2] * b.z);
+    const V3 ga = add(scale(2.f * g_xx, Va), scale(g_xy, Vb));
+    const V3 gb = add(scale(2.f * g_yy, Vb), scale(g_xy, Va));
+    // a = J00 w0 + J02 w2, b = J11 w1 + J12 w2
+    const V3 w0 = v3(e.W.c[0][0], e.W.c[0][1], e.W.c[0][2]);
+    const V3 w1 = v3(e.W.c[1][0], e.W.c[1][1], e.W.c[1][2]);
+    const V3 w2 = v3(e.W.c[2][0], e.W.c[2][1], e.W.c[2][2]);
+    const float gJ00 = dot(w0, ga), gJ02 = dot(w2, ga), gJ11 = dot(w1, gb), gJ12 = dot(w2, gb);
+    // J00 = fx / tz, J02 = -fx tx / tz^2, J11 = fy / tz, J12 = -fy ty / tz^2, with tx, ty clamped to the
+    // 1.3 x frustum: a clamped coordinate passes no gradient to itself (the reference also drops its
+    // dependence on tz, backward.cu:185-186, 313-315; so does this)
     const V3 t = e.t;
-    const float x_grad_mul = (e.txtz < -e.limx || e.txtz > e.limx) ? 0.f : 1.f;
-    const float y_grad_mul = (e.tytz < -e.limy || e.tytz > e.limy) ? 0.f : 1.f;
-    const float (*T)[3] = e.T.c;
-    const float (*W)[3] = e.W.c;
-    const float (*Vrk)[3] = e.Vrk.c;
-
-    float c_xx = e.cxx, c_xy = e.cxy, c_yy = e.cyy;
-    const float h_var = 0.3f;
-    float d_inside_root = 0.f;
-    if (c.antialiasing) {
-        const float det_cov = c_xx * c_yy - c_xy * c_xy;
-        c_xx += h_var;
-        c_yy += h_var;
-        const float det_h = c_xx * c_yy - c_xy * c_xy;
-        const float hcs = sqrtf(fmax_(0.000025f, det_cov / det_h));
-        const float dop = *dopacity;
-        const float d_hcs = dop * opacity;
-        *dopacity = dop * hcs;
-        d_inside_root = (det_cov / det_h) <= 0.000025f ? 0.f : d_hcs / (2 * hcs);
-    } else {
-        c_xx += h_var;
-        c_yy += h_var;
-    }
-
-    float dL_dc_xx = 0, dL_dc_xy = 0, dL_dc_yy = 0;
-    if (c.antialiasing) {
-        const float x = c_xx, y = c_yy, z = c_xy, w = h_var;
-        const float q = w * w + w * (x + y) + x * y - z * z;
-        const float denom_f = d_inside_root / (q * q);
-        dL_dc_xx = w * (w * y + y * y + z * z) * denom_f;
-        dL_dc_yy = w * (w * x + x * x + z * z) * denom_f;
-        dL_dc_xy = -2.f * w * z * (w + x + y) * denom_f;
-    }
-
-    const float denom = c_xx * c_yy - c_xy * c_xy;
-    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-    if (denom2inv != 0) {
-        dL_dc_xx += denom2inv * (-c_yy * c_yy * dconic.x + 2 * c_xy * c_yy * dconic.y + (denom - c_xx * c_yy) * dconic.z);
-        dL_dc_yy += denom2inv * (-c_xx * c_xx * dconic.z + 2 * c_xx * c_xy * dconic.y + (denom - c_xx * c_yy) * dconic.x);
-        dL_dc_xy += denom2inv * 2 * (c_xy * c_yy * dconic.x - (denom + 2 * c_xy * c_xy) * dconic.y + c_xx * c_xy * dconic.z);
-
-        dcov6[0] = (T[0][0] * T[0][0] * dL_dc_xx + T[0][0] * T[1][0] * dL_dc_xy + T[1][0] * T[1][0] * dL_dc_yy);
-        dcov6[3] = (T[0][1] * T[0][1] * dL_dc_xx + T[0][1] * T[1][1] * dL_dc_xy + T[1][1] * T[1][1] * dL_dc_yy);
-        dcov6[5] = (T[0][2] * T[0][2] * dL_dc_xx + T[0][2] * T[1][2] * dL_dc_xy + T[1][2] * T[1][2] * dL_dc_yy);
-        dcov6[1] = 2 * T[0][0] * T[0][1] * dL_dc_xx + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_dc_xy + 2 * T[1][0] * T[1][1] * dL_dc_yy;
-        dcov6[2] = 2 * T[0][0] * T[0][2] * dL_dc_xx + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_dc_xy + 2 * T[1][0] * T[1][2] * dL_dc_yy;
-        dcov6[4] = 2 * T[0][2] * T[0][1] * dL_dc_xx + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_dc_xy + 2 * T[1][1] * T[1][2] * dL_dc_yy;
-    } else {
-        for (int i = 0; i < 6; i++) dcov6[i] = 0;
-    }
-
-    const float dL_dT00 = 2 * (T[0][0] * Vrk[0][0] + T[0][1] * Vrk[0][1] + T[0][2] * Vrk[0][2]) * dL_dc_xx +
-                          (T[1][0] * Vrk[0][0] + T[1][1] * Vrk[0][1] + T[1][2] * Vrk[0][2]) * dL_dc_xy;
-    const float dL_dT01 = 2 * (T[0][0] * Vrk[1][0] + T[0][1] * Vrk[1][1] + T[0][2] * Vrk[1][2]) * dL_dc_xx +
-                          (T[1][0] * Vrk[1][0] + T[1][1] * Vrk[1][1] + T[1][2] * Vrk[1][2]) * dL_dc_xy;
-    const float dL_dT02 = 2 * (T[0][0] * Vrk[2][0] + T[0][1] * Vrk[2][1] + T[0][2] * Vrk[2][2]) * dL_dc_xx +
-                          (T[1][0] * Vrk[2][0] + T[1][1] * Vrk[2][1] + T[1][2] * Vrk[2][2]) * dL_dc_xy;
-    const float dL_dT10 = 2 * (T[1][0] * Vrk[0][0] + T[1][1] * Vrk[0][1] + T[1][2] * Vrk[0][2]) * dL_dc_yy +
-                          (T[0][0] * Vrk[0][0] + T[0][1] * Vrk[0][1] + T[0][2] * Vrk[0][2]) * dL_dc_xy;
-    const float dL_dT11 = 2 * (T[1][0] * Vrk[1][0] + T[1][1] * Vrk[1][1] + T[1][2] * Vrk[1][2]) * dL_dc_yy +
-                          (T[0][0] * Vrk[1][0] + T[0][1] * Vrk[1][1] + T[0][2] * Vrk[1][2]) * dL_dc_xy;
-    const float dL_dT12 = 2 * (T[1][0] * Vrk[2][0] + T[1][1] * Vrk[2][1] + T[1][2] * Vrk[2][2]) * dL_dc_yy +
-                          (T[0][0] * Vrk[2][0] + T[0][1] * Vrk[2][1] + T[0][2] * Vrk[2][2]) * dL_dc_xy;
-
-    const float dL_dJ00 = W[0][0] * dL_dT00 + W[0][1] * dL_dT01 + W[0][2] * dL_dT02;
-    const float dL_dJ02 = W[2][0] * dL_dT00 + W[2][1] * dL_dT01 + W[2][2] * dL_dT02;
-    const float dL_dJ11 = W[1][0] * dL_dT10 + W[1][1] * dL_dT11 + W[1][2] * dL_dT12;
-    const float dL_dJ12 = W[2][0] * dL_dT10 + W[2][1] * dL_dT11 + W[2][2] * dL_dT12;
-
-    const float tz = 1.f / t.z;
-    const float tz2 = tz * tz;
-    const float tz3 = tz2 * tz;
-
-    const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
-    const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
-    float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
-    if (dinvdepth) dL_dtz -= *dinvdepth / (t.z * t.z);
-
-    return xform_vec_4x3_T(v3(dL_dtx, dL_dty, dL_dtz), c.view);
+    const float inside_x = (e.txtz < -e.limx || e.txtz > e.limx) ? 0.f : 1.f;
+    const float inside_y = (e.tytz < -e.limy || e.tytz > e.limy) ? 0.f : 1.f;
+    const float iz = 1.f / t.z, iz2 = iz * iz, iz3 = iz2 * iz;
+    const float g_tx = inside_x * (-fx * iz2) * gJ02;
+    const float g_ty = inside_y * (-fy * iz2) * gJ12;
+    float g_tz = -fx * iz2 * gJ00 - fy * iz2 * gJ11 + (2 * fx * t.x) * iz3 * gJ02 + (2 * fy * t.y) * iz3 * gJ12;
+    if (dinvdepth) g_tz -= *dinvdepth / (t.z * t.z);   // the rendered inverse depth is 1 / t.z per Gaussian
+    return xform_vec_4x3_T(v3(g_tx, g_ty, g_tz), c.view);
 }
 
 // backward.cu:429-443: gradient of the 3D mean through the 2D mean.
