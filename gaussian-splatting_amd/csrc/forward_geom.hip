@@ -212,7 +212,13 @@ struct PreBatchArgs {
     FwdBatchView v[MAX_FWD_BATCH_VIEWS];
 };
 
-__global__ void __launch_bounds__(PRE_BLOCK, 2) preprocess_fwd_batch_kernel(const PreBatchArgs b) {
+#ifndef PRE_FWD_BATCH_WAVES
+#define PRE_FWD_BATCH_WAVES 2
+#endif
+#ifndef PRE_FWD_BATCH_UNROLL
+#define PRE_FWD_BATCH_UNROLL 1
+#endif
+__global__ void __launch_bounds__(PRE_BLOCK, PRE_FWD_BATCH_WAVES) preprocess_fwd_batch_kernel(const PreBatchArgs b) {
     __shared__ __align__(16) char s_sh[4 * REST_WAVE_F * 4];
     __shared__ uint32_t s_tiles[MAX_FWD_BATCH_VIEWS][4];
     __shared__ uint32_t s_vis[MAX_FWD_BATCH_VIEWS][4];
@@ -271,7 +277,7 @@ __global__ void __launch_bounds__(PRE_BLOCK, 2) preprocess_fwd_batch_kernel(cons
     float4 rp = make_float4(0, 0, 0, 0);
     if (b.DIM == 4) rp = reinterpret_cast<const float4*>(b.reps)[i];
 
-#pragma unroll 1
+#pragma unroll PRE_FWD_BATCH_UNROLL
     for (int v = 0; v < b.nviews; ++v) {
         const FwdBatchView& bv = b.v[v];
         uint32_t tiles = 0;
