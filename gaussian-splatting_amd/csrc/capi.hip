@@ -494,6 +494,38 @@ int gso_densify_stats(int P, const int* radii, const float* dL_dmeans2D, float* 
                                            (hipStream_t)stream));
 }
 
+int gso_densify_select(int64_t N, int64_t n_grads, const float* xyz_gradient_accum, const float* denom,
+                       const float* scaling, float grad_threshold, float size_threshold, int split, uint8_t* selected,
+                       void* stream) {
+    if (N < 0 || n_grads < 0 || n_grads > N) return GSR_ERR_ARG;
+    if (N == 0) return GSR_OK;
+    if (!scaling || !selected || (n_grads > 0 && (!xyz_gradient_accum || !denom))) return GSR_ERR_ARG;
+    return hip_status(launch_densify_select(N, n_grads, xyz_gradient_accum, denom, scaling, grad_threshold,
+                                            size_threshold, split ? 1 : 0, selected, (hipStream_t)stream));
+}
+
+int gso_prune_mask(int64_t N, const float* opacity, const float* max_radii2D, const float* scaling, float min_opacity,
+                   float max_screen_size, float max_world_size, const uint8_t* also, uint8_t* mask, void* stream) {
+    if (N < 0) return GSR_ERR_ARG;
+    if (N == 0) return GSR_OK;
+    if (!opacity || !mask) return GSR_ERR_ARG;
+    if (max_screen_size > 0.0f && (!max_radii2D || !scaling)) return GSR_ERR_ARG;
+    return hip_status(launch_prune_mask(N, opacity, max_radii2D, scaling, min_opacity, max_screen_size, max_world_size,
+                                        also, mask, (hipStream_t)stream));
+}
+
+int gso_split_children(int64_t K, int n, const uint32_t* parents, const float* xyz, const float* scaling,
+                       const float* rotation, const float* normals, float* new_xyz, float* new_scaling,
+                       uint32_t* parent_of_child, void* stream) {
+    if (K < 0 || n <= 0) return GSR_ERR_ARG;
+    if (K == 0) return GSR_OK;
+    if (K * (int64_t)n >= (1ll << 31)) return GSR_ERR_OVERFLOW;
+    if (!parents || !xyz || !scaling || !rotation || !normals || !new_xyz || !new_scaling || !parent_of_child)
+        return GSR_ERR_ARG;
+    return hip_status(launch_split_children(K, n, parents, xyz, scaling, rotation, normals, new_xyz, new_scaling,
+                                            parent_of_child, (hipStream_t)stream));
+}
+
 size_t gso_compact_temp_bytes(int64_t N) { return compact_temp_bytes(N > 0 ? N : 1); }
 
 int gso_compact_map(int64_t N, const uint8_t* keep, uint32_t* src_of_dst, void* temp, size_t temp_bytes, int64_t* kept,

@@ -140,6 +140,15 @@ hipError_t launch_adam(float* param, const float* grad, float* exp_avg, float* e
 hipError_t launch_densify_stats(int P, const int* radii, const float* dL_dmeans2D, float* xyz_gradient_accum,
                                 float* denom, float* max_radii2D, hipStream_t st);
 
+hipError_t launch_densify_select(int64_t N, int64_t n_grads, const float* xyz_gradient_accum, const float* denom,
+                                 const float* scaling, float grad_threshold, float size_threshold, int split,
+                                 uint8_t* selected, hipStream_t st);
+hipError_t launch_prune_mask(int64_t N, const float* opacity, const float* max_radii2D, const float* scaling,
+                             float min_opacity, float max_screen_size, float max_world_size, const uint8_t* also,
+                             uint8_t* mask, hipStream_t st);
+hipError_t launch_split_children(int64_t K, int n, const uint32_t* parents, const float* xyz, const float* scaling,
+                                 const float* rotation, const float* normals, float* new_xyz, float* new_scaling,
+                                 uint32_t* parent_of_child, hipStream_t st);
 hipError_t launch_scan_u32(uint32_t* sums, int nb, uint64_t* total, hipStream_t st);
 size_t compact_temp_bytes(int64_t N);
 hipError_t launch_compact_map(int64_t N, const uint8_t* keep, uint32_t* src_of_dst, void* temp, hipStream_t st,

@@ -134,6 +134,116 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const uint32_t* __rest
     dst[i] = src[(int64_t)src_of_dst[r] * M + c];
 }
 
+// ------------------------------------------------------------------ densification: who is cloned, split, pruned
+// GaussianModel.densify_and_prune (scene/gaussian_model.py:216-252) decides per Gaussian from the
+// accumulated screen-space gradient norm and from its size:
+//   grads = xyz_gradient_accum / denom, NaN -> 0                                    (:224-225)
+//   clone:  |grads| >= grad_threshold  and  max(exp(scaling)) <= size_threshold      (:263-270)
+//   split:  grads  >= grad_threshold  and  max(exp(scaling)) >  size_threshold       (:356-364)
+// with size_threshold = percent_dense * scene_extent.  The split is decided after the clones were
+// appended, with the gradients padded by zeros for them: rows at and beyond n_grads have gradient 0.
+// The reference does it with a dozen elementwise kernels and temporaries; this is one pass.
+__global__ void __launch_bounds__(256) densify_select_kernel(int64_t N, int64_t n_grads,
+                                                             const float* __restrict__ xyz_gradient_accum,
+                                                             const float* __restrict__ denom,
+                                                             const float* __restrict__ scaling, float grad_threshold,
+                                                             float size_threshold, int split,
+                                                             uint8_t* __restrict__ selected) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float g = 0.0f;
+    if (i < n_grads) {
+        g = xyz_gradient_accum[i] / denom[i];
+        if (g != g) g = 0.0f;
+    }
+    const float smax = fmaxf(fmaxf(expf(scaling[3 * i]), expf(scaling[3 * i + 1])), expf(scaling[3 * i + 2]));
+    bool sel;
+    if (split) sel = g >= grad_threshold && smax > size_threshold;
+    else sel = sqrtf(g * g) >= grad_threshold && smax <= size_threshold;
+    selected[i] = sel ? 1 : 0;
+}
+
+// The prune decision of densify_and_prune (scene/gaussian_model.py:237-244): opacity below the
+// minimum, or (when a screen-size limit is given) too large on screen or in the world; `also`
+// (nullable) is OR-ed in: the parents a split has just replaced (:388-392).
+__global__ void __launch_bounds__(256) prune_mask_kernel(int64_t N, const float* __restrict__ opacity,
+                                                         const float* __restrict__ max_radii2D,
+                                                         const float* __restrict__ scaling, float min_opacity,
+                                                         float max_screen_size, float max_world_size,
+                                                         const uint8_t* __restrict__ also, uint8_t* __restrict__ mask) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    bool m = (1.0f / (1.0f + expf(-opacity[i]))) < min_opacity;
+    if (max_screen_size > 0.0f) {
+        const float smax = fmaxf(fmaxf(expf(scaling[3 * i]), expf(scaling[3 * i + 1])), expf(scaling[3 * i + 2]));
+        m = m || max_radii2D[i] > max_screen_size || smax > max_world_size;
+    }
+    if (also) m = m || also[i] != 0;
+    mask[i] = m ? 1 : 0;
+}
+
+// densify_and_split (scene/gaussian_model.py:367-377): every selected Gaussian is replaced by n
+// children.  Child j (of K * n, laid out as `.repeat(n, 1)` lays them out: child j belongs to parent
+// j mod K) sits at parent position + R(q / |q|) (z_j * exp(scaling)), z_j a standard normal sample
+// the caller brings (torch.normal(0, std) is z * std), and has scale exp(scaling) / (0.8 n), stored
+// as its logarithm.  parent_of_child[j] is written for the plain row copies of the other tensors.
+__global__ void __launch_bounds__(256) split_children_kernel(int64_t K, int n, const uint32_t* __restrict__ parents,
+                                                             const float* __restrict__ xyz,
+                                                             const float* __restrict__ scaling,
+                                                             const float* __restrict__ rotation,
+                                                             const float* __restrict__ normals,
+                                                             float* __restrict__ new_xyz, float* __restrict__ new_scaling,
+                                                             uint32_t* __restrict__ parent_of_child) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= K * n) return;
+    const uint32_t p = parents[j % K];
+    parent_of_child[j] = p;
+    const float sx = expf(scaling[3 * (size_t)p]), sy = expf(scaling[3 * (size_t)p + 1]), sz = expf(scaling[3 * (size_t)p + 2]);
+    const float ox = normals[3 * j] * sx, oy = normals[3 * j + 1] * sy, oz = normals[3 * j + 2] * sz;
+    // utils/general_utils.py:87-108 (build_rotation): normalised quaternion (r, x, y, z) to a matrix
+    float r = rotation[4 * (size_t)p], x = rotation[4 * (size_t)p + 1], y = rotation[4 * (size_t)p + 2],
+          z = rotation[4 * (size_t)p + 3];
+    const float norm = sqrtf(r * r + x * x + y * y + z * z);
+    r /= norm; x /= norm; y /= norm; z /= norm;
+    const float R00 = 1 - 2 * (y * y + z * z), R01 = 2 * (x * y - r * z), R02 = 2 * (x * z + r * y);
+    const float R10 = 2 * (x * y + r * z), R11 = 1 - 2 * (x * x + z * z), R12 = 2 * (y * z - r * x);
+    const float R20 = 2 * (x * z - r * y), R21 = 2 * (y * z + r * x), R22 = 1 - 2 * (x * x + y * y);
+    new_xyz[3 * j] = (R00 * ox + R01 * oy + R02 * oz) + xyz[3 * (size_t)p];
+    new_xyz[3 * j + 1] = (R10 * ox + R11 * oy + R12 * oz) + xyz[3 * (size_t)p + 1];
+    new_xyz[3 * j + 2] = (R20 * ox + R21 * oy + R22 * oz) + xyz[3 * (size_t)p + 2];
+    const float shrink = 0.8f * (float)n;
+    new_scaling[3 * j] = logf(sx / shrink);
+    new_scaling[3 * j + 1] = logf(sy / shrink);
+    new_scaling[3 * j + 2] = logf(sz / shrink);
+}
+
+hipError_t launch_densify_select(int64_t N, int64_t n_grads, const float* xyz_gradient_accum, const float* denom,
+                                 const float* scaling, float grad_threshold, float size_threshold, int split,
+                                 uint8_t* selected, hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(densify_select_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, n_grads,
+                       xyz_gradient_accum, denom, scaling, grad_threshold, size_threshold, split, selected);
+    return hipGetLastError();
+}
+
+hipError_t launch_prune_mask(int64_t N, const float* opacity, const float* max_radii2D, const float* scaling,
+                             float min_opacity, float max_screen_size, float max_world_size, const uint8_t* also,
+                             uint8_t* mask, hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(prune_mask_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, opacity, max_radii2D,
+                       scaling, min_opacity, max_screen_size, max_world_size, also, mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_children(int64_t K, int n, const uint32_t* parents, const float* xyz, const float* scaling,
+                                 const float* rotation, const float* normals, float* new_xyz, float* new_scaling,
+                                 uint32_t* parent_of_child, hipStream_t st) {
+    if (K <= 0 || n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(split_children_kernel, dim3((unsigned)((K * n + 255) / 256)), dim3(256), 0, st, K, n, parents, xyz,
+                       scaling, rotation, normals, new_xyz, new_scaling, parent_of_child);
+    return hipGetLastError();
+}
+
 size_t compact_temp_bytes(int64_t N) {
     const size_t nb = (size_t)((N + 255) / 256);
     return align_up((nb + 1) * sizeof(uint32_t), 256) + 4 * sizeof(uint64_t);

@@ -18,6 +18,11 @@ SUPPORTED_DIMS = (0, 4)
 # arguments the reference does not have (split SH tensors, raw parameters, prepared views, gradient
 # buffers to write into).
 try:
+    import os as _os
+    if _os.environ.get("GSPLAT_AMD_LIB"):
+        # a library override (A/B runs of kernel variants): the extension is linked against the in-tree
+        # library, so everything goes through ctypes and the one library that was asked for
+        raise ImportError("library override")
     from . import _hip_ext
 except ImportError:
     _hip_ext = None

@@ -173,3 +173,140 @@ def cat_tensors_to_optimizer(optimizer, tensors_dict):
         group["params"][0] = new_p
         optimizable[group["name"]] = new_p
     return optimizable
+
+
+# ---------------------------------------------------------------- densification (clone / split / prune)
+def _f32(t, shape, what):
+    if tuple(t.shape) != tuple(shape) or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise RuntimeError(f"{what}: expected a contiguous float32 GPU tensor of shape {tuple(shape)}, "
+                           f"got {tuple(t.shape)} {t.dtype} on {t.device}")
+    return t
+
+
+@torch.no_grad()
+def densify_select(xyz_gradient_accum, denom, scaling, grad_threshold, size_threshold, split, n_grads=None):
+    """The clone (split=False, scene/gaussian_model.py:263-270) or split (split=True, :356-364) selection as a
+    bool mask over the N rows of `scaling` (raw log-scales), in one kernel: gradient = accum / denom with
+    NaN -> 0 for the first `n_grads` rows (default: all), 0 for the rest; size_threshold = percent_dense * extent."""
+    N = scaling.shape[0]
+    n_grads = N if n_grads is None else int(n_grads)
+    _f32(scaling, (N, 3), "scaling")
+    sel = torch.empty((N,), dtype=torch.uint8, device=scaling.device)
+    with torch.cuda.device(scaling.device):
+        check(lib().gso_densify_select(N, n_grads, xyz_gradient_accum.data_ptr() if n_grads else None,
+                                       denom.data_ptr() if n_grads else None, scaling.data_ptr(), float(grad_threshold),
+                                       float(size_threshold), int(bool(split)), sel.data_ptr(), stream_of(scaling.device)),
+              "densify select")
+    return sel.view(torch.bool)
+
+
+@torch.no_grad()
+def prune_mask(opacity, max_radii2D, scaling, min_opacity, max_screen_size, extent, also=None):
+    """The prune decision of scene/gaussian_model.py:237-244 (+ the rows of `also`) as a bool mask, one kernel."""
+    N = opacity.shape[0]
+    m = torch.empty((N,), dtype=torch.uint8, device=opacity.device)
+    al = None if also is None else also.contiguous().view(torch.uint8)
+    with torch.cuda.device(opacity.device):
+        check(lib().gso_prune_mask(N, opacity.contiguous().data_ptr(), max_radii2D.data_ptr(), scaling.data_ptr(),
+                                   float(min_opacity), float(max_screen_size) if max_screen_size else 0.0,
+                                   0.1 * float(extent), None if al is None else al.data_ptr(), m.data_ptr(),
+                                   stream_of(opacity.device)), "prune mask")
+    return m.view(torch.bool)
+
+
+@torch.no_grad()
+def split_children(parents, n, xyz, scaling, rotation, normals):
+    """Positions and log-scales of the K * n children of the K parents (row indices, int32, ascending)
+    as scene/gaussian_model.py:367-377 forms them, `normals` = the [K*n, 3] standard normal samples;
+    also returns parent_of_child [K*n] (int32) for copying the other tensors' rows."""
+    K = parents.shape[0]
+    dev = xyz.device
+    new_xyz = torch.empty((K * n, 3), dtype=torch.float32, device=dev)
+    new_scaling = torch.empty((K * n, 3), dtype=torch.float32, device=dev)
+    poc = torch.empty((K * n,), dtype=torch.int32, device=dev)
+    if K:
+        _f32(normals, (K * n, 3), "normals")
+        with torch.cuda.device(dev):
+            check(lib().gso_split_children(K, int(n), parents.data_ptr(), xyz.data_ptr(), scaling.data_ptr(),
+                                           rotation.data_ptr(), normals.data_ptr(), new_xyz.data_ptr(),
+                                           new_scaling.data_ptr(), poc.data_ptr(), stream_of(dev)), "split children")
+    return new_xyz, new_scaling, poc
+
+
+def _take_rows(t, rows):
+    """t[rows] for an int32 row list through the row-gather kernel."""
+    K = rows.shape[0]
+    out = torch.empty((K,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    M = t.numel() // max(t.shape[0], 1)
+    if K and M:
+        if t.element_size() != 4 or not t.is_contiguous():
+            return t[rows.long()]
+        with torch.cuda.device(t.device):
+            check(lib().gso_gather_rows(t.data_ptr(), out.data_ptr(), rows.data_ptr(), K, M, stream_of(t.device)),
+                  "gather rows")
+    return out
+
+
+@torch.no_grad()
+def densify_and_prune(optimizer, stats, max_grad, min_opacity, extent, max_screen_size, radii, percent_dense=0.01,
+                      n_split=2, normals=None):
+    """GaussianModel.densify_and_prune (scene/gaussian_model.py:216-252) on an optimizer whose param groups carry
+    the reference's names ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "reps"; one tensor each):
+    clone the small Gaussians with a large view-space gradient, split the large ones into `n_split` children,
+    prune the transparent and the oversized, with the Adam moments following every row.  `stats` is a dict with
+    xyz_gradient_accum [N,1], denom [N,1], max_radii2D [N]; `radii` the last forward's radii (the reference's
+    tmp_radii).  `normals`: the standard normal samples for the split, [n_split * (number split), 3] or a
+    callable (rows) -> tensor; default torch.randn.  The selections, the split and the prune mask are one
+    kernel each, every row list is resolved once (one host block per stage) and applied to all tensors.
+    Returns ({group name: new parameter}, new stats dict, radii of the surviving rows)."""
+    by_name = {g["name"]: g for g in optimizer.param_groups}
+    P = lambda name: by_name[name]["params"][0]
+    accum, den = stats["xyz_gradient_accum"], stats["denom"]
+    N0 = P("xyz").shape[0]
+    size_thr = percent_dense * extent
+    tmp_radii = radii
+
+    def append(rows_src, overrides):
+        ext = {}
+        for name in by_name:
+            ext[name] = overrides[name] if name in overrides else _take_rows(P(name).data, rows_src)
+        return cat_tensors_to_optimizer(optimizer, ext)
+
+    # clone (:254-283)
+    sel = densify_select(accum, den, P("scaling").data, max_grad, size_thr, split=False)
+    comp = RowCompactor(sel)
+    rows = comp.index[:comp.kept]
+    if comp.kept:
+        append(rows, {})
+        tmp_radii = torch.cat((tmp_radii, _take_rows(tmp_radii, rows)))
+    # split (:347-392): decided on the grown model, gradients padded with zeros for the clones
+    sel = densify_select(accum, den, P("scaling").data, max_grad, size_thr, split=True, n_grads=N0)
+    comp = RowCompactor(sel)
+    rows = comp.index[:comp.kept]
+    also = None
+    if comp.kept:
+        K = comp.kept
+        z = normals(K * n_split) if callable(normals) else normals
+        if z is None:
+            z = torch.randn((K * n_split, 3), device=sel.device)
+        new_xyz, new_scaling, poc = split_children(rows, n_split, P("xyz").data, P("scaling").data, P("rotation").data,
+                                                   z.contiguous())
+        append(poc, {"xyz": new_xyz, "scaling": new_scaling})
+        tmp_radii = torch.cat((tmp_radii, _take_rows(tmp_radii, poc)))
+        also = torch.cat((sel, torch.zeros(K * n_split, dtype=torch.bool, device=sel.device)))
+    # densification_postfix restarts the statistics at the new size whether or not rows were appended
+    # (:318-320), max_radii2D included: the screen-size test below therefore reads zeros, as it does in the
+    # reference, and the returned statistics are zeros of the final size.
+    N2 = P("xyz").shape[0]
+    dev = P("xyz").device
+    max_radii2D = torch.zeros((N2,), device=dev)
+    # prune: the parents a split replaced (:388-392) and the transparent / oversized (:237-247), decided per
+    # row, so one compaction serves both (the reference prunes twice; the surviving rows and their order are
+    # the same)
+    mask = prune_mask(P("opacity").data.view(-1), max_radii2D, P("scaling").data, min_opacity, max_screen_size, extent,
+                      also=also)
+    optimizable, comp = prune_optimizer(optimizer, ~mask)
+    n = comp.kept
+    new_stats = dict(xyz_gradient_accum=torch.zeros((n, 1), device=dev), denom=torch.zeros((n, 1), device=dev),
+                     max_radii2D=torch.zeros((n,), device=dev))
+    return optimizable, new_stats, comp(tmp_radii)

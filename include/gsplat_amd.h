@@ -347,6 +347,32 @@ int gso_adam_update(float* param, const float* grad, float* exp_avg, float* exp_
 int gso_densify_stats(int P, const int* radii, const float* dL_dmeans2D, float* xyz_gradient_accum, float* denom,
                       float* max_radii2D, void* stream);
 
+/* Densification decisions and the split, each in one pass (GaussianModel.densify_and_prune,
+ * scene/gaussian_model.py:216-252, which the reference runs as dozens of elementwise PyTorch kernels
+ * with boolean-mask temporaries).  All pointers are device pointers; scaling [N,3] holds log-scales,
+ * opacity [N] logits, rotation [N,4] unnormalised quaternions, as the model stores them.
+ *   gso_densify_select: selected[i] = 1 for the Gaussians to clone (split == 0: |g| >= grad_threshold and
+ *     max(exp(scaling)) <= size_threshold, :263-270) or to split (split != 0: g >= grad_threshold and
+ *     max(exp(scaling)) > size_threshold, :356-364), g = xyz_gradient_accum / denom with NaN -> 0
+ *     (:224-225) for rows below n_grads and 0 for the rows beyond (the clones appended since, :356-357);
+ *     size_threshold = percent_dense * scene_extent.
+ *   gso_prune_mask: mask[i] = sigmoid(opacity) < min_opacity, OR-ed, when max_screen_size > 0, with
+ *     max_radii2D > max_screen_size and max(exp(scaling)) > max_world_size (= 0.1 * extent) (:237-244),
+ *     and with also[i] (nullable: the parents a split replaced, :388-392).
+ *   gso_split_children: the K * n children of the K selected parents (`parents`: their row indices,
+ *     ascending), child j of parent j mod K as `.repeat(n, 1)` orders them (:367-377): new_xyz =
+ *     xyz[parent] + R(q / |q|) (normals[j] * exp(scaling[parent])) with normals [K*n,3] standard normal
+ *     samples from the caller, new_scaling = log(exp(scaling[parent]) / (0.8 n)); parent_of_child [K*n] is
+ *     written for gso_gather_rows to copy the other tensors' rows. */
+int gso_densify_select(int64_t N, int64_t n_grads, const float* xyz_gradient_accum, const float* denom,
+                       const float* scaling, float grad_threshold, float size_threshold, int split, uint8_t* selected,
+                       void* stream);
+int gso_prune_mask(int64_t N, const float* opacity, const float* max_radii2D, const float* scaling, float min_opacity,
+                   float max_screen_size, float max_world_size, const uint8_t* also, uint8_t* mask, void* stream);
+int gso_split_children(int64_t K, int n, const uint32_t* parents, const float* xyz, const float* scaling,
+                       const float* rotation, const float* normals, float* new_xyz, float* new_scaling,
+                       uint32_t* parent_of_child, void* stream);
+
 /* Row compaction for pruning (scene/gaussian_model.py:402-441, which keeps the rows of a mask in
  * every parameter, Adam moment and statistics tensor by boolean indexing: one host-blocking
  * nonzero() and one gather per tensor).  gso_compact_map turns the mask (device [N] bytes, nonzero =

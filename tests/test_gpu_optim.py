@@ -187,3 +187,136 @@ def test_prune_and_cat_match_the_reference_formulation():
     for g in a.param_groups:   # the optimizer still steps after the surgery
         g["params"][0].grad = torch.randn_like(g["params"][0])
     a.step()
+
+
+def _reference_densify_and_prune(model, opt, max_grad, min_opacity, extent, max_screen_size, radii, percent_dense, N,
+                                 normals):
+    """GaussianModel.densify_and_prune / densify_and_clone / densify_and_split / prune_points
+    (scene/gaussian_model.py:216-425) restated on a dict of tensors with plain PyTorch, statement by statement;
+    the split's torch.normal(mean=0, std=stds) is taken as normals * stds with the normals handed in."""
+    import torch.nn as nn
+    names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "reps")
+
+    def param(n):
+        return [g for g in opt.param_groups if g["name"] == n][0]["params"][0]
+
+    def cat(d):
+        for g in opt.param_groups:
+            ext = d[g["name"]]
+            p = g["params"][0]
+            st = opt.state.get(p, None)
+            newp = nn.Parameter(torch.cat((p.data, ext), dim=0).requires_grad_(True))
+            if st is not None:
+                st["exp_avg"] = torch.cat((st["exp_avg"], torch.zeros_like(ext)), dim=0)
+                st["exp_avg_sq"] = torch.cat((st["exp_avg_sq"], torch.zeros_like(ext)), dim=0)
+                del opt.state[p]
+                opt.state[newp] = st
+            g["params"][0] = newp
+
+    def prune(mask):
+        keep = ~mask
+        for g in opt.param_groups:
+            p = g["params"][0]
+            st = opt.state.get(p, None)
+            newp = nn.Parameter(p.data[keep].requires_grad_(True))
+            if st is not None:
+                st["exp_avg"] = st["exp_avg"][keep]
+                st["exp_avg_sq"] = st["exp_avg_sq"][keep]
+                del opt.state[p]
+                opt.state[newp] = st
+            g["params"][0] = newp
+        for k in ("xyz_gradient_accum", "denom", "max_radii2D", "tmp_radii"):
+            model[k] = model[k][keep]
+
+    def postfix(d, new_radii):
+        cat(d)
+        n = param("xyz").shape[0]
+        model["tmp_radii"] = torch.cat((model["tmp_radii"], new_radii))
+        model["xyz_gradient_accum"] = torch.zeros((n, 1), device="cuda")
+        model["denom"] = torch.zeros((n, 1), device="cuda")
+        model["max_radii2D"] = torch.zeros((n,), device="cuda")
+
+    grads = model["xyz_gradient_accum"] / model["denom"]
+    grads[grads.isnan()] = 0.0
+    model["tmp_radii"] = radii
+    # clone
+    sel = torch.where(torch.norm(grads, dim=-1) >= max_grad, True, False)
+    sel = torch.logical_and(sel, torch.max(torch.exp(param("scaling").data), dim=1).values <= percent_dense * extent)
+    postfix({n: param(n).data[sel] for n in names}, model["tmp_radii"][sel])
+    # split
+    n_init = param("xyz").shape[0]
+    padded = torch.zeros((n_init,), device="cuda")
+    padded[:grads.shape[0]] = grads.squeeze()
+    sel = torch.where(padded >= max_grad, True, False)
+    sel = torch.logical_and(sel, torch.max(torch.exp(param("scaling").data), dim=1).values > percent_dense * extent)
+    stds = torch.exp(param("scaling").data)[sel].repeat(N, 1)
+    samples = normals[: stds.shape[0]] * stds
+    q = param("rotation").data[sel]
+    qn = q / torch.sqrt(q[:, 0] * q[:, 0] + q[:, 1] * q[:, 1] + q[:, 2] * q[:, 2] + q[:, 3] * q[:, 3])[:, None]
+    r, x, y, z = qn[:, 0], qn[:, 1], qn[:, 2], qn[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
+    rots = R.repeat(N, 1, 1)
+    d = {n: param(n).data[sel].repeat(*([N] + [1] * (param(n).dim() - 1))) for n in names}
+    d["xyz"] = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + param("xyz").data[sel].repeat(N, 1)
+    d["scaling"] = torch.log(torch.exp(param("scaling").data)[sel].repeat(N, 1) / (0.8 * N))
+    postfix(d, model["tmp_radii"][sel].repeat(N))
+    prune(torch.cat((sel, torch.zeros(N * int(sel.sum()), device="cuda", dtype=bool))))
+    # prune
+    mask = (torch.sigmoid(param("opacity").data) < min_opacity).squeeze()
+    if max_screen_size:
+        big_vs = model["max_radii2D"] > max_screen_size
+        big_ws = torch.exp(param("scaling").data).max(dim=1).values > 0.1 * extent
+        mask = torch.logical_or(torch.logical_or(mask, big_vs), big_ws)
+    prune(mask)
+    return int(sel.sum())
+
+
+@pytest.mark.parametrize("max_screen_size", [None, 20])
+def test_densify_and_prune_matches_the_reference_formulation(max_screen_size):
+    """gsplat_optim.densify_and_prune (selection, split and prune-mask kernels + one row compaction per stage)
+    against the reference's method restated above: the same rows in the same order in every parameter and Adam
+    moment (bit for bit where rows are copied; the split children's positions and scales to 1e-6, a matrix
+    product and a logarithm)."""
+    import gsplat_optim
+    g = torch.Generator(device="cuda").manual_seed(5)
+    N, extent, pd = 5000, 4.0, 0.01
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    base = dict(xyz=rnd(N, 3), f_dc=rnd(N, 1, 3), f_rest=rnd(N, 15, 3), opacity=rnd(N, 1) * 3 - 2,
+                scaling=rnd(N, 3) * 0.8 + np.log(pd * extent), rotation=rnd(N, 4), reps=rnd(N, 4))
+    accum = torch.rand(N, 1, device="cuda", generator=g) * 0.001
+    denom = torch.randint(0, 4, (N, 1), device="cuda", generator=g).float()      # zeros give NaN gradients
+    radii = torch.randint(0, 40, (N,), device="cuda", generator=g).int()
+    normals = rnd(2 * N, 3)
+
+    def make():
+        params = {k: torch.nn.Parameter(v.clone()) for k, v in base.items()}
+        opt = torch.optim.Adam([{"params": [p], "lr": 1e-3, "name": k} for k, p in params.items()], eps=1e-15)
+        for p in params.values():            # moments that can be told apart
+            p.grad = torch.sin(p.data * 3)
+        opt.step()
+        return opt
+
+    ref_opt, opt = make(), make()
+    model = dict(xyz_gradient_accum=accum.clone(), denom=denom.clone(), max_radii2D=torch.rand(N, device="cuda") * 30)
+    n_split = _reference_densify_and_prune(model, ref_opt, 0.0004, 0.05, extent, max_screen_size, radii.clone(), pd, 2,
+                                           normals)
+    stats = dict(xyz_gradient_accum=accum.clone(), denom=denom.clone(), max_radii2D=torch.rand(N, device="cuda") * 30)
+    new_params, new_stats, new_radii = gsplat_optim.densify_and_prune(
+        opt, stats, 0.0004, 0.05, extent, max_screen_size, radii.clone(), percent_dense=pd, n_split=2,
+        normals=lambda n: normals[:n].contiguous())
+    torch.cuda.synchronize()
+    assert n_split > 100
+    for gr, gg in zip(ref_opt.param_groups, opt.param_groups):
+        name = gr["name"]
+        pr, pg = gr["params"][0], gg["params"][0]
+        assert pr.shape == pg.shape and pg.shape[0] != N, name
+        assert new_params[name] is pg
+        tol = dict(rtol=1e-6, atol=1e-6) if name in ("xyz", "scaling") else dict(rtol=0, atol=0)
+        assert torch.allclose(pg.data, pr.data, **tol), name
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(opt.state[pg][k], ref_opt.state[pr][k]), (name, k)
+    assert torch.equal(new_radii, model["tmp_radii"])
+    for k in ("xyz_gradient_accum", "denom", "max_radii2D"):
+        assert torch.equal(new_stats[k], model[k]), k

@@ -26,7 +26,13 @@ def stats(sc, W, H):
     gx, gy = (W + 15) // 16, (H + 15) // 16
     n = o["img"][lay.n_contrib:lay.n_contrib + W * H * 4].view(torch.int32).reshape(H, W)
     n = torch.nn.functional.pad(n, (0, gx * 16 - W, 0, gy * 16 - H))
-    walked = int(n.reshape(gy, 16, gx, 16).amax(dim=(1, 3)).sum(dtype=torch.int64))
+    per_tile = n.reshape(gy, 16, gx, 16).amax(dim=(1, 3)).reshape(-1).float()
+    walked = int(per_tile.sum(dtype=torch.float64))
+    q = torch.quantile(per_tile, torch.tensor([0.5, 0.9, 0.99, 1.0], device=per_tile.device)).tolist()
+    print("   walked per tile: median %.0f, p90 %.0f, p99 %.0f, max %.0f; list length max %d" %
+          (q[0], q[1], q[2], q[3], int((o["img"][lay.ranges:lay.ranges + gx * gy * 8].view(torch.int32).reshape(-1, 2)[:, 1] -
+                                         o["img"][lay.ranges:lay.ranges + gx * gy * 8].view(torch.int32).reshape(-1, 2)[:, 0]).max())))
+    # per quadrant (8x8) share of instances whose splat reaches it with alpha >= 1/255 is not observable here
     vis = int((o["radii"] > 0).sum())
     pairs = int(o["gauss_count"].sum(dtype=torch.int64))
     return dict(visible=vis, R=R, R_per_visible=round(R / max(vis, 1), 2), walked=walked, walked_over_R=round(walked / max(R, 1), 3),
