@@ -358,7 +358,10 @@ onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* 
 #define GS_EP_THREADS 512
 #endif
 constexpr int EP_THREADS = GS_EP_THREADS;
-constexpr int EP_ITEMS = 8;
+#ifndef GS_EP_ITEMS
+#define GS_EP_ITEMS 8
+#endif
+constexpr int EP_ITEMS = GS_EP_ITEMS;
 constexpr int EP_CHUNK = EP_THREADS * EP_ITEMS;  // instances per chunk
 constexpr int EP_MAX_BLOCKS = EP_CHUNK / 256 + 1;
 constexpr int EP_MAX_PER = (EP_MAX_BLOCKS * 256 + EP_THREADS - 1) / EP_THREADS;

@@ -44,6 +44,8 @@ class GradReducer:
         self.group = group
         self.average = average
         self.pending = []
+        self.coalesce = hasattr(dist, "_coalescing_manager")
+        self.calls = 0
 
     def _active(self):
         return dist.is_initialized() and dist.get_world_size(self.group) > 1
@@ -73,11 +75,25 @@ class GradReducer:
             for t in rows:
                 self._staged(t)
             return self
-        # one coalesced collective for the seven row blocks (a single grouped launch with RCCL)
-        with dist._coalescing_manager(group=self.group, async_ops=True) as cm:
-            for t in rows:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        self.pending.append((rows, cm))
+        # one coalesced collective for the seven row blocks (a single grouped launch with RCCL); a backend or
+        # PyTorch build without coalescing gets one asynchronous all-reduce per block instead
+        if self.coalesce:
+            try:
+                with dist._coalescing_manager(group=self.group, async_ops=True) as cm:
+                    for t in rows:
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                self.pending.append((rows, cm))
+                self.calls += 1
+                return self
+            except (AttributeError, RuntimeError, ValueError, TypeError, NotImplementedError):
+                # nothing was issued if entering or leaving the manager failed before the collective started;
+                # a failure after a partial issue would double-count, so only the first call may fall back
+                if self.pending or self.calls:
+                    raise
+                self.coalesce = False
+        self.calls += 1
+        for t in rows:
+            self.pending.append(([t], dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
         return self
 
     def wait(self):
