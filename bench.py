@@ -7,8 +7,10 @@ does with the three operator packages on one view of a synthetic 6M-Gaussian
 street scene at 1920x1080 (SH degree 3, 4 `reps` channels, antialiasing on):
 activations -> rasterizer forward -> L1 + fused-ssim loss -> rasterizer
 backward.  A step is a batch of V views per GPU (default 8, different cameras)
-whose parameter gradients accumulate, followed with N > 1 by one RCCL sum
-all-reduce of the 63 floats per Gaussian.  The forward preprocess and the
+whose parameter gradients accumulate, followed with N > 1 by the RCCL sum
+all-reduce of the 63 floats per Gaussian (of every Gaussian, or with --reduce
+auto / sparse of the Gaussians that some view of the step, on any rank,
+reached: the other rows are zero everywhere).  The forward preprocess and the
 per-Gaussian backward of the V views each run as one batch kernel per step, and
 the views in between are dealt to a few HIP streams (default 3) so that their
 kernels overlap.  Every rank holds a full replica and renders its own cameras:
@@ -368,6 +370,10 @@ def main():
     ap.add_argument("--reduce-chunks", type=int, default=6,
                     help="n_gpus > 1: ranges of Gaussians the per-Gaussian backward runs over, the all-reduce of each "
                          "range's gradient rows starting as soon as its launch is enqueued (1 = one all-reduce after it)")
+    ap.add_argument("--reduce", choices=("auto", "dense", "sparse"), default="auto",
+                    help="n_gpus > 1: what the gradient exchange carries.  dense: every row; sparse: the rows of the "
+                         "Gaussians some view of the step (any rank) reached; auto: sparse while those are at most "
+                         "35 %% of the rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-view / reference-API / FPS measurements")
     ap.add_argument("--fwd-only", action="store_true", help="time rendering only (render FPS)")
@@ -432,8 +438,8 @@ def main():
 
     host_wait = [0.0]
 
-    reducer = gsdp.GradReducer()
-    grad_tensors = sink.tensors() if use_params else None
+    reducer = gsdp.GradReducer(sparse={"auto": "auto", "dense": "never", "sparse": "always"}[args.reduce])
+    reduce_modes = []
 
     def step(k=None, timer=None, overlap=True):
         # the views are dealt to the current stream and the side streams in turn (only when the per-Gaussian
@@ -477,17 +483,21 @@ def main():
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
         if use_params:
-            # the per-Gaussian backward range by range; each range's rows go to RCCL (its own stream) as soon
-            # as the launch is enqueued and are exchanged while the later ranges are computed
-            sink.flush(chunks=args.reduce_chunks,
-                       on_chunk=lambda first, count: reducer.start_rows(grad_tensors, first, count))
+            # Few Gaussians reached by the views of this step (all ranks): only their gradient rows are
+            # exchanged.  Otherwise the per-Gaussian backward runs range by range; each range's rows go to
+            # RCCL (its own stream) as soon as the launch is enqueued and are exchanged while the later ranges
+            # are computed.  e1: the compute stream's own work of the step ends, from there it waits for the
+            # exchange.
+            mode = gsdp.reduce_flush(sink, reducer, chunks=args.reduce_chunks, after_flush=e1.record)
         else:
             reducer.start([p.grad for p in leaves])
-        e1.record()       # the compute stream's own work of the step ends here
-        reducer.wait()    # ... and from here it waits for the exchange
+            e1.record()
+            reducer.wait()
+            mode = "dense"
         e2.record()
         if k is not None:
             reducer_ms.append((e0, e1, e2))
+            reduce_modes.append(mode)
         return out
 
     def sync():
@@ -503,6 +513,7 @@ def main():
     for _ in range(max(args.warmup, 3)):
         out = step(0, timer)
     reducer_ms.clear()
+    reduce_modes.clear()
     sync()
     host_wait[0] = 0.0
     t0 = time.perf_counter()
@@ -771,8 +782,8 @@ def main():
             "config": {"workload": f"{args.scene if args.scene != 'street' else 'street scene'}"
                                    f"{' street scene (small, mostly transparent splats)' if args.scene == 'translucent' else ''}, {P} Gaussians SH3 + 4 reps, {W}x{H}, antialiasing; a step = {V} views "
                                    f"per GPU (different cameras, gradients accumulate)" +
-                                   (", forward only" if args.fwd_only else ", each fwd + fused-ssim loss + bwd, then one "
-                                    "gradient all-reduce when n_gpus > 1; no optimizer"),
+                                   (", forward only" if args.fwd_only else ", each fwd + fused-ssim loss + bwd, then the "
+                                    "sum of the gradients over the GPUs when n_gpus > 1 (see allreduce); no optimizer"),
                        "api": "forward_params (raw parameters)" if use_params else "reference signature",
                        "streams": 1 + len(side_streams),
                        "loss": ("fused_ssim.l1_ssim_loss + fused_ssim.l1_loss on the reps" if fused_loss else
@@ -815,7 +826,14 @@ def main():
                 # one all-reduce of the whole flat gradient buffer with nothing else running
                 "standalone_ms": allreduce_alone_ms,
                 "bus_GBps": (2.0 * (world - 1) / world * nbytes / (allreduce_alone_ms * 1e-3) / 1e9)
-                            if allreduce_alone_ms else None}
+                            if allreduce_alone_ms else None,
+                # what the timed steps exchanged: every row ("dense") or the rows of the Gaussians that the
+                # views of the step, over all ranks, reached ("sparse"; rows, of how many, at the last probe)
+                "policy": args.reduce,
+                "steps_dense": reduce_modes.count("dense"), "steps_sparse": reduce_modes.count("sparse"),
+                "union_rows": reducer.last_union[0] if reducer.last_union else None,
+                "union_fraction": (reducer.last_union[0] / max(1, reducer.last_union[1])) if reducer.last_union else None,
+                "bytes_sparse": (reducer.last_union[0] * (nbytes // max(1, P)) + P) if reducer.last_union else None}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(P, W, H, seed, args.scene == "translucent")

@@ -147,6 +147,7 @@ class ParamGradSink:
             features_dc.size(1) + features_rest.size(1) == 16
         self.pending = []
         self.prepared = []
+        self.hit_counts = []
 
     def attach(self):
         """(Re-)install the buffers as the parameters' `.grad`: `optimizer.zero_grad(set_to_none=True)`
@@ -163,6 +164,7 @@ class ParamGradSink:
         """The next backward overwrites the buffers, the ones after it accumulate."""
         self.pending = []
         self.prepared = []
+        self.hit_counts = []
         self.fresh = True
         self.attach()
 
@@ -258,6 +260,18 @@ class ParamGradSink:
     def tensors(self):
         return list(self.grads.values())
 
+    def touched_rows(self):
+        """uint8 [P]: 1 for the Gaussians whose gradient rows can be non-zero in this step, i.e. that
+        some pixel of some view rendered since `begin_step()` reached while it still accepted
+        contributions (`gauss_count` != 0, forward.cu:423-432).  Every gradient of a Gaussian comes
+        from such a pixel (backward.cu:591-611 walks the same pairs), so the rows of all other
+        Gaussians are exactly zero: a data-parallel caller exchanges only the union of these rows."""
+        P = self.num_gaussians()
+        t = torch.zeros((P,), dtype=torch.uint8, device=self.flat.device)
+        for c in self.hit_counts:
+            t |= c.view(-1).ne(0)
+        return t
+
 
 class _RasterizeGaussiansParams(torch.autograd.Function):
     """The same operator on the model's raw parameters: the SH tensors stay
@@ -283,6 +297,7 @@ class _RasterizeGaussiansParams(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.sink = sink
         ctx.means2D = means2D
+        ctx.gauss_count = gauss_count if sink is not None else None
         ctx.save_for_backward(xyz, scaling, rotation, radii, features_dc, features_rest, opacity, geomBuffer,
                               binningBuffer, imgBuffer, reps)
         return color, radii, invdepths, gauss_sum, gauss_count, out_reps
@@ -296,6 +311,8 @@ class _RasterizeGaussiansParams(torch.autograd.Function):
                                                                      grad_out_reps)
         sink = ctx.sink
         empty = torch.Tensor([])
+        if sink is not None:
+            sink.hit_counts.append(ctx.gauss_count)
         if sink is not None and sink.defer:
             g_means2D, work = _C.rasterize_gaussians_backward_blend(
                 rs.bg, xyz, radii, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix, rs.projmatrix,

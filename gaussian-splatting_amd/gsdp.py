@@ -38,22 +38,45 @@ class GradReducer:
     on_chunk=...)` the rows of a range of Gaussians go out as soon as the launch
     that completes them is enqueued, and their exchange overlaps the per-Gaussian
     backward of the remaining ranges.  `wait()` makes the current stream (gloo:
-    the host) wait for everything started."""
+    the host) wait for everything started.
 
-    def __init__(self, group=None, average=False):
+    Sparse exchange.  A view only gives gradients to the Gaussians its pixels
+    reached, and in a large or heavily occluded scene the views of a step reach
+    a small part of the model; all other rows are exactly zero on every rank.
+    `plan_rows(touched)` takes this rank's uint8 row mask (`ParamGradSink.
+    touched_rows()`), forms the union over the ranks (one MAX all-reduce of P
+    bytes), and returns the row indices of the union when it is at most
+    `sparse_below` of the rows, else None; `start_gathered(tensors, rows)` then
+    exchanges only those rows, packed into one [n, row width] buffer, and
+    `wait()` writes the sums back.  The result equals the dense all-reduce:
+    the rows left out are zero everywhere.  `plan_rows` blocks the host (the
+    row count sizes the collective, and every rank must take the same branch);
+    `sparse`: "auto" probes every step while the union stays sparse and
+    every `probe_every` steps after three dense steps in a row, "always" never
+    falls back, "never" makes `plan_rows` return None without communication."""
+
+    def __init__(self, group=None, average=False, sparse="auto", sparse_below=0.35, probe_every=16):
+        if sparse not in ("auto", "always", "never"):
+            raise ValueError("GradReducer: sparse must be 'auto', 'always' or 'never'")
         self.group = group
         self.average = average
         self.pending = []
         self.coalesce = hasattr(dist, "_coalescing_manager")
         self.calls = 0
+        self.sparse = sparse
+        self.sparse_below = float(sparse_below)
+        self.probe_every = max(1, int(probe_every))
+        self.dense_streak = 0
+        self.plans = 0
+        self.last_union = None      # (rows in the union, rows) of the last probe
 
     def _active(self):
         return dist.is_initialized() and dist.get_world_size(self.group) > 1
 
-    def _staged(self, t):
+    def _staged(self, t, op=dist.ReduceOp.SUM):
         """gloo rehearsal of the multi-rank path on GPU tensors: through host memory, synchronously."""
         h = t.cpu()
-        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(h, op=op, group=self.group)
         t.copy_(h)
 
     def start(self, tensors):
@@ -96,13 +119,65 @@ class GradReducer:
             self.pending.append(([t], dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
         return self
 
+    def plan_rows(self, touched):
+        """touched: uint8 [P], non-zero where this rank's gradient rows may be non-zero, or a function
+        that returns it (only called when the mask is needed); every rank calls this in every step, with
+        its own mask.  Returns the int64 indices of the rows in the
+        union over the ranks, or None when the exchange should be dense."""
+        if not self._active() or self.sparse == "never":
+            return None
+        self.plans += 1
+        if self.sparse == "auto" and self.dense_streak >= 3 and self.plans % self.probe_every != 0:
+            return None
+        if callable(touched):
+            touched = touched()
+        union = touched if touched.dtype == torch.uint8 else touched.ne(0).to(torch.uint8)
+        if dist.get_backend(self.group) == "gloo" and union.is_cuda:
+            self._staged(union, dist.ReduceOp.MAX)
+        else:
+            dist.all_reduce(union, op=dist.ReduceOp.MAX, group=self.group)
+        rows = torch.nonzero(union).view(-1)            # host-synchronous: the size of the exchange
+        self.last_union = (int(rows.numel()), int(union.numel()))
+        if self.sparse == "auto" and rows.numel() > self.sparse_below * union.numel():
+            self.dense_streak += 1
+            return None
+        self.dense_streak = 0
+        return rows
+
+    def start_gathered(self, tensors, rows):
+        """Sum over the ranks of the rows `rows` (from `plan_rows`: the same indices on every rank) of
+        every tensor ([P, ...] each); the other rows must be zero on every rank and stay as they are."""
+        if not self._active() or rows.numel() == 0:
+            return self
+        cols = [t.view(t.size(0), -1) for t in tensors if t is not None and t.numel() != 0]
+        packed = torch.cat([c.index_select(0, rows) for c in cols], dim=1)
+
+        def put_back():
+            at = 0
+            for c in cols:
+                c.index_copy_(0, rows, packed[:, at:at + c.size(1)])
+                at += c.size(1)
+
+        if dist.get_backend(self.group) == "gloo" and packed.is_cuda:
+            self._staged(packed)
+            if self.average:
+                packed.div_(dist.get_world_size(self.group))
+            put_back()
+            return self
+        work = dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.pending.append(([packed], work, put_back))
+        return self
+
     def wait(self):
         ws = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        for ts, work in self.pending:
+        for entry in self.pending:
+            ts, work = entry[0], entry[1]
             work.wait()
             if self.average:
                 for t in ts:
                     t.div_(ws)
+            if len(entry) > 2:
+                entry[2]()
         self.pending = []
 
 
@@ -130,9 +205,8 @@ def run_views(sink, settings_list, loss_of_view, streams=(), reducer=None, chunk
     The side streams are only used with a deferring sink: without deferral every view's backward
     writes the shared gradient buffers, which is only ordered on one stream.
 
-    reducer: a `GradReducer`; the flush then runs over `chunks` ranges of Gaussians and the
-    all-reduce of each range's gradient rows starts as soon as its launch is enqueued; the call
-    returns after `reducer.wait()`.  Returns the detached losses."""
+    reducer: a `GradReducer`; the flush and the exchange of the gradients then go through
+    `reduce_flush(sink, reducer, chunks)`.  Returns the detached losses."""
     sink.begin_step()
     sink.prepare_views(settings_list)
     main = torch.cuda.current_stream()
@@ -154,10 +228,33 @@ def run_views(sink, settings_list, loss_of_view, streams=(), reducer=None, chunk
     if reducer is None:
         sink.flush()
     else:
-        grads = sink.tensors()
-        sink.flush(chunks=chunks, on_chunk=lambda first, count: reducer.start_rows(grads, first, count))
-        reducer.wait()
+        reduce_flush(sink, reducer, chunks)
     return losses
+
+
+def reduce_flush(sink, reducer, chunks=6, after_flush=None):
+    """`sink.flush()` followed by the sum of the parameter gradients over the ranks; returns when the
+    current stream has the sums.  When the views of this step (all ranks) reached few enough
+    Gaussians, only the rows of those are exchanged (`GradReducer.plan_rows`); otherwise the flush
+    runs over `chunks` ranges of Gaussians and each range's rows are exchanged while the later
+    ranges are computed.  `after_flush()`, if given, is called when the per-Gaussian backward has been
+    enqueued (a place to record an event).  Returns "sparse" or "dense"."""
+    grads = sink.tensors()
+    rows = reducer.plan_rows(sink.touched_rows)
+    if rows is not None:
+        sink.flush()
+        if after_flush is not None:
+            after_flush()
+            after_flush = None
+        reducer.start_gathered(grads, rows)
+        mode = "sparse"
+    else:
+        sink.flush(chunks=chunks, on_chunk=lambda first, count: reducer.start_rows(grads, first, count))
+        mode = "dense"
+    if after_flush is not None:
+        after_flush()
+    reducer.wait()
+    return mode
 
 
 def view_sharded_step(params, views, loss_of_view, group=None):

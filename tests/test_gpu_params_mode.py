@@ -493,6 +493,9 @@ def test_run_views_variants(nviews, nstreams, defer, chunks):
             assert all(x.size(0) == 700 for x in tensors)
             self.rows.append((first, count))
 
+        def plan_rows(self, touched):   # always the dense exchange
+            return None
+
         def wait(self):
             pass
 
@@ -511,3 +514,50 @@ def test_run_views_variants(nviews, nstreams, defer, chunks):
         ga, gb = A[n].grad.cpu().numpy(), B[n].grad.cpu().numpy()
         assert np.isfinite(gb).all(), n
         assert rel_err(gb, ga) <= REL_TOL, (n, rel_err(gb, ga))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("defer", [True, False])
+def test_untouched_rows_have_zero_gradients(defer):
+    """What the sparse gradient exchange of gsdp.GradReducer rests on: a Gaussian that no live pixel of any
+    view of the step reached (gauss_count == 0 in all of them, forward.cu:423-432) has all-zero gradient
+    rows, and `ParamGradSink.touched_rows()` is exactly the OR of the views' gauss_count != 0."""
+    import gsdp
+    from diff_gaussian_rasterization import GaussianRasterizer, ParamGradSink
+    W, H = 96, 64
+    sc = synth.tiny_scene(P=3000, width=W, height=H, seed=47)
+    raw = _raw_scene(sc, seed=9)
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda:0")
+    names = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation", "reps")
+    vals = (sc["means3D"], raw["features_dc"], raw["features_rest"], raw["opacity"], raw["scaling"], raw["rotation"],
+            sc["reps"])
+    A = {n: t(v).requires_grad_(True) for n, v in zip(names, vals)}
+    sink = ParamGradSink(*[A[n] for n in names], defer=defer)
+    settings = _arc_settings(3, W, H)
+    rng = np.random.default_rng(19)
+    ws = [[t(rng.standard_normal(s).astype(np.float32)) for s in ((3, H, W), (1, H, W), (4, H, W))] for _ in range(3)]
+    counts = []
+
+    def f(i, rs):
+        m2 = torch.zeros_like(A["xyz"], requires_grad=True)
+        o = GaussianRasterizer(rs).forward_params(A["xyz"], m2, A["features_dc"], A["features_rest"], A["opacity"],
+                                                  A["scaling"], A["rotation"], A["reps"], grad_sink=sink)
+        counts.append(o[4])
+        return (o[0] * ws[i][0]).sum() + (o[2] * ws[i][1]).sum() + (o[5] * ws[i][2]).sum()
+
+    sink.flat.fill_(float("nan"))
+    gsdp.run_views(sink, settings, f, [torch.cuda.Stream()])
+    touched = sink.touched_rows()
+    torch.cuda.synchronize()
+    want = torch.stack([c != 0 for c in counts]).any(0)
+    assert torch.equal(touched.bool(), want)
+    n_touched = int(want.sum())
+    assert 0 < n_touched < 3000, n_touched      # the scene has both kinds
+    for k, g in sink.grads.items():
+        g2 = g.view(g.size(0), -1)
+        assert torch.isfinite(g2).all(), k
+        assert not g2[~want].any(), (k, "a Gaussian no pixel reached has a non-zero gradient row")
+    assert sink.grads["sh"].view(3000, -1)[want].abs().sum() > 0
+    # the next step starts from an empty record
+    sink.begin_step()
+    assert not sink.touched_rows().any()

@@ -110,12 +110,13 @@ def _make_fake_sink(params):
 
         def _geometry(self, cfg, views, first, count, accumulate):
             self.launches.append((first, count, len(views), accumulate))
-            for k, g in self.grads.items():
-                rows = sum(_view_grad(self.params[k], v["w"])[first:first + count] for v in views)
-                if accumulate:
-                    g[first:first + count] += rows
-                else:
-                    g[first:first + count] = rows
+            with torch.no_grad():
+                for k, g in self.grads.items():
+                    rows = sum(_view_grad(self.params[k], v["w"])[first:first + count] for v in views)
+                    if accumulate:
+                        g[first:first + count] += rows
+                    else:
+                        g[first:first + count] = rows
 
     leaves = [params[k].clone().requires_grad_(True) for k in ("xyz", "dc", "rest", "opacity", "scaling", "rotation", "reps")]
     sink = FakeSink(*leaves, defer=True)
@@ -192,3 +193,77 @@ def test_param_grad_sink_flat_buffer_and_reattach():
     sink.params["means3D"] = torch.zeros(7, 3)
     with pytest.raises(RuntimeError):
         sink.begin_step()
+
+
+# ---------------------------------------------------------------- sparse exchange of the touched rows
+def _sparse_views(P, nviews, density):
+    """Per-view row weights that are zero outside a random subset of the rows (the Gaussians a view reached)."""
+    g = torch.Generator().manual_seed(11)
+    out = []
+    for _ in range(nviews):
+        w = torch.randn(P, generator=g)
+        w[torch.rand(P, generator=g) >= density] = 0.0
+        out.append(w)
+    return out
+
+
+def _sparse_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gsdp
+    params, _ = _sink_problem()
+    out = {}
+    for name, density, mode in (("sparse_auto", 0.03, "auto"), ("dense_auto", 0.6, "auto"), ("dense_forced_sparse", 0.6, "always"),
+                                ("never", 0.03, "never"), ("nothing_touched", 0.0, "auto")):
+        views = _sparse_views(1000, 5, density)
+        sink, leaves = _make_fake_sink(params)
+        sink.begin_step()
+        sink.flat.fill_(float("nan"))
+        for vi in gsdp.shard_views(5, rank, world):
+            sink.pending.append(dict(cfg=(1.0, 3, False), w=views[vi], means2D=torch.zeros(3, requires_grad=True),
+                                     dL_dmeans2D=torch.ones(3)))
+            sink.hit_counts.append(views[vi].ne(0).to(torch.int32))   # what the forward's gauss_count says
+        red = gsdp.GradReducer(sparse=mode)
+        took = gsdp.reduce_flush(sink, red, chunks=3)
+        out[name] = dict(grads=[p.grad.clone() for p in leaves], took=took, union=red.last_union,
+                         launches=len(sink.launches))
+        type(sink).launches.clear()
+    # three dense steps in a row: the fourth one does not probe (no mask exchange), the 16th plan does
+    red = gsdp.GradReducer(sparse="auto", probe_every=4)
+    dense = torch.ones(1000, dtype=torch.uint8)
+    calls = []
+
+    def mask():
+        calls.append(1)
+        return dense.clone()
+
+    for _ in range(8):
+        assert red.plan_rows(mask) is None
+    out["probes"] = len(calls)
+    torch.save(out, os.path.join(out_dir, f"p{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sparse_row_exchange_world2(tmp_path):
+    world = 2
+    mp.start_processes(_sparse_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True,
+                       start_method="spawn")
+    params, _ = _sink_problem()
+    order = ("xyz", "dc", "rest", "opacity", "scaling", "rotation", "reps")
+    expect = dict(sparse_auto=("sparse", 0.03), dense_auto=("dense", 0.6), dense_forced_sparse=("sparse", 0.6),
+                  never=("dense", 0.03), nothing_touched=("sparse", 0.0))
+    for r in range(world):
+        got = torch.load(os.path.join(tmp_path, f"p{r}.pt"), weights_only=True)
+        for name, (took, density) in expect.items():
+            views = _sparse_views(1000, 5, density)
+            assert got[name]["took"] == took, (name, got[name]["took"])
+            for g, k in zip(got[name]["grads"], order):
+                ref = sum(_view_grad(params[k], v) for v in views)
+                assert torch.allclose(g, ref, rtol=1e-5, atol=1e-6), (name, k, r)
+            if name != "never":
+                union = int(torch.stack([v.ne(0) for v in views]).any(0).sum())
+                assert tuple(got[name]["union"]) == (union, 1000)
+        # the sparse path flushes in one launch, the dense one in three ranges
+        assert got["sparse_auto"]["launches"] == 1 and got["dense_auto"]["launches"] == 3
+        # 8 plans with probe_every 4: plans 1-3 probe (streak builds), then only plans 4 and 8
+        assert got["probes"] == 5
