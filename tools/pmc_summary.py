@@ -4,7 +4,9 @@ profiles/pmc_traffic.json (HBM bytes per launch per kernel, FETCH_SIZE doubled
 as measured for wide coalesced reads on gfx950, WRITE_SIZE as is; both are
 reported in KiB by rocprofv3).
 
-usage: python tools/pmc_summary.py TAG
+usage: python tools/pmc_summary.py TAG [TRAFFIC_JSON]
+TRAFFIC_JSON (default pmc_traffic.json, which bench.py reads for the default workload) names the
+traffic file under profiles/; give another name for a collection on another scene.
 """
 import csv
 import glob
@@ -48,6 +50,7 @@ COMPOSED = {
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    traffic_json = sys.argv[2] if len(sys.argv) > 2 else "pmc_traffic.json"
     acc = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> values per dispatch
     newest = {}   # one file per pass: the latest (earlier collections may have left theirs behind)
     for path in glob.glob(os.path.join(SRC, "*", "**", "*counter_collection.csv"), recursive=True):
@@ -79,7 +82,7 @@ def main():
             continue
         per_launch = (2.0 * sum(fs) / len(fs) + sum(ws) / len(ws)) * 1024.0
         traffic[k] = per_launch
-    with open(os.path.join(ROOT, "profiles", "pmc_traffic_detail.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", traffic_json.replace(".json", "_detail.json")), "w") as f:
         json.dump({k: traffic[k] for k in sorted(traffic)}, f, indent=1)
     simple = {k: v for k, v in traffic.items() if ":" not in k}
     for name, parts in COMPOSED.items():
@@ -110,11 +113,12 @@ def main():
             ent["clock_GHz"] = (sum(ga) / len(ga)) / 8.0 / dur_ns[k]
         valu[k] = ent
     out_d["_valu"] = valu
-    out_d["_workload"] = [6000000, 1920, 1080]   # bench.py defaults, which tools/collect_pmc.sh runs
+    # bench.py defaults, which tools/collect_pmc.sh runs; another scene's file is never bench.py's default one
+    out_d["_workload"] = [6000000, 1920, 1080] if traffic_json == "pmc_traffic.json" else traffic_json
     out_d["_note"] = "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB, mean over the launches of the PMC passes"
-    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", traffic_json), "w") as f:
         json.dump(out_d, f, indent=1)
-    print("wrote profiles/pmc_traffic.json", simple)
+    print("wrote profiles/" + traffic_json, simple)
     # kernel stats of the trace pass
     stats = sorted(glob.glob(os.path.join(SRC, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     for path in stats[-1:]:
