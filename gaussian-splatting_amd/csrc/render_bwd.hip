@@ -143,63 +143,69 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
             float4 q3 = make_float4(0, 0, 0, 0);
             if (DIM == 4) q3 = s_q3[j];
 
-            float g_mx = 0.f, g_my = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_op = 0.f;
-            f2 g_rg = {0.f, 0.f}, g_bd = {0.f, 0.f}, g_r01 = {0.f, 0.f}, g_r23 = {0.f, 0.f};
-
-            if (lane_in(vm)) {
-                // 1 / (1 - alpha): v_rcp_f32 plus one Newton step (two fused multiply-adds).  The bare
-                // v_rcp_f32 (1 ulp, not unbiased) is not enough: T is recovered by one such division
-                // per blended Gaussian, its error grows along the list, and in gradients that are small
-                // sums of large terms it showed up as 3e-4 relative against a divide; with the step
-                // the results match an IEEE divide (ten instructions) within the 1e-4 bar element-wise.
-                const float oma = 1.f - alpha;
-                float inv_1ma = __builtin_amdgcn_rcpf(oma);
-                inv_1ma = fmaf(fmaf(-oma, inv_1ma, 1.0f), inv_1ma, inv_1ma);
-                T = T * inv_1ma;
-                const float dchannel_dcolor = alpha * T;
-                const f2 dc2 = {dchannel_dcolor, dchannel_dcolor};
-                // The reference keeps, per channel, accum = last_alpha * last_c + (1 - last_alpha) * accum
-                // and adds (c - accum) * dL_dpixel over the channels (backward.cu:618-660).  Only the
-                // sum is used, and it obeys the same recurrence with S = sum_ch c * dL_dpixel in the
-                // place of c: two scalars of state per pixel instead of two per channel.  S is summed
-                // two channels at a time.
-                f2 S2 = (f2){q2.x, q2.y} * D01;
-                S2 = __builtin_elementwise_fma((f2){q2.z, q2.w}, D2i, S2);
-                g_rg = dc2 * D01;
-                g_bd = dc2 * D2i;
-                if (DIM == 4) {
-                    S2 = __builtin_elementwise_fma((f2){q3.x, q3.y}, E01, S2);
-                    S2 = __builtin_elementwise_fma((f2){q3.z, q3.w}, E23, S2);
-                    g_r01 = dc2 * E01;
-                    g_r23 = dc2 * E23;
-                }
-                const float S = S2.x + S2.y;
-                accum_S = fmaf(last_alpha, last_S - accum_S, accum_S);
-                last_S = S;
-                float dL_dalpha = S - accum_S;
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
-
-                g_op = G * dL_dalpha;
-                const float dL_dG = co.w * dL_dalpha;
-                const float gdx = G * dx;
-                const float gdy = G * dy;
-                const float dG_ddelx = -gdx * co.x - gdy * co.y;
-                const float dG_ddely = -gdy * co.z - gdx * co.y;
-                g_mx = dL_dG * dG_ddelx * ddelx_dx;
-                g_my = dL_dG * dG_ddely * ddely_dy;
-                g_cx = -0.5f * gdx * dx * dL_dG;
-                g_cy = -0.5f * gdx * dy * dL_dG;
-                g_cw = -0.5f * gdy * dy * dL_dG;
+            // No branch around the arithmetic: a pixel outside vm takes part as a contributor with
+            // alpha = 0 and G = 0.  Its transmittance stays as it is (T / (1 - 0), exactly), all 14
+            // gradient terms come out as exact zeros (each is a product with alpha or G), and the
+            // recurrence below only moves the update it would have made at its next real contributor
+            // forward: accum_S takes the value it would take there, and with last_alpha = 0 every later
+            // step until then is accum_S + 0 * (...) = accum_S.  Same results bit for bit as skipping
+            // the pixel, without the 14 registers that would have to be zeroed for the skipped lanes
+            // before the reduction (a wave instruction costs the same with 1 or 64 lanes enabled).
+            const float alpha_e = select_or_zero(vm, alpha);
+            const float G_e = select_or_zero(vm, G);
+            // 1 / (1 - alpha): v_rcp_f32 plus one Newton step (two fused multiply-adds).  The bare
+            // v_rcp_f32 (1 ulp, not unbiased) is not enough: T is recovered by one such division
+            // per blended Gaussian, its error grows along the list, and in gradients that are small
+            // sums of large terms it showed up as 3e-4 relative against a divide; with the step
+            // the results match an IEEE divide (ten instructions) within the 1e-4 bar element-wise.
+            const float oma = 1.f - alpha_e;
+            float inv_1ma = __builtin_amdgcn_rcpf(oma);
+            inv_1ma = fmaf(fmaf(-oma, inv_1ma, 1.0f), inv_1ma, inv_1ma);
+            T = T * inv_1ma;
+            const float dchannel_dcolor = alpha_e * T;
+            const f2 dc2 = {dchannel_dcolor, dchannel_dcolor};
+            // The reference keeps, per channel, accum = last_alpha * last_c + (1 - last_alpha) * accum
+            // and adds (c - accum) * dL_dpixel over the channels (backward.cu:618-660).  Only the
+            // sum is used, and it obeys the same recurrence with S = sum_ch c * dL_dpixel in the
+            // place of c: two scalars of state per pixel instead of two per channel.  S is summed
+            // two channels at a time.
+            f2 S2 = (f2){q2.x, q2.y} * D01;
+            S2 = __builtin_elementwise_fma((f2){q2.z, q2.w}, D2i, S2);
+            const f2 g_rg = dc2 * D01;
+            const f2 g_bd = dc2 * D2i;
+            f2 g_r01 = {0.f, 0.f}, g_r23 = {0.f, 0.f};
+            if (DIM == 4) {
+                S2 = __builtin_elementwise_fma((f2){q3.x, q3.y}, E01, S2);
+                S2 = __builtin_elementwise_fma((f2){q3.z, q3.w}, E23, S2);
+                g_r01 = dc2 * E01;
+                g_r23 = dc2 * E23;
             }
+            const float S = S2.x + S2.y;
+            accum_S = fmaf(last_alpha, last_S - accum_S, accum_S);
+            last_S = S;
+            float dL_dalpha = S - accum_S;
+            dL_dalpha *= T;
+            last_alpha = alpha_e;
+            dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
+
+            const float g_op = G_e * dL_dalpha;
+            const float dL_dG = co.w * dL_dalpha;
+            const float gdx = G_e * dx;
+            const float gdy = G_e * dy;
+            const float dG_ddelx = -gdx * co.x - gdy * co.y;
+            const float dG_ddely = -gdy * co.z - gdx * co.y;
+            const float g_mx = dL_dG * dG_ddelx * ddelx_dx;
+            const float g_my = dL_dG * dG_ddely * ddely_dy;
+            const float g_cx = -0.5f * gdx * dx * dL_dG;
+            const float g_cy = -0.5f * gdx * dy * dL_dG;
+            const float g_cw = -0.5f * gdy * dy * dL_dG;
 
             // 16 gradient components x 64 pixels -> 16 sums: transpose-reduce inside each
             // row of 16 lanes, fold the four rows with two lane swaps, then 16 lanes add
             // to 16 different LDS words (the four waves of the tile meet there).
             const float comp[16] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_rg.x, g_rg.y, g_bd.x, g_bd.y,
                                     g_r01.x, g_r01.y, g_r23.x, g_r23.y, 0.f, 0.f};
-            const float tot = rows_sum4(row_transpose_sum16(comp, lane));
+const float tot = rows_sum4(row_transpose_sum16(comp, lane));
             if (lane < 16) atomicAdd(&s_acc[j][lane], tot);
         }
         __syncthreads();
