@@ -139,14 +139,18 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
                 if (bm == 0) continue;
                 const float4 q2 = s_q2[j];
                 if (lane_in(bm)) {
-                    // forward.cu:454-464: c * alpha * T per channel, two channels per instruction
-                    const f2 a2 = {alpha, alpha}, T2 = {T, T};
-                    Crg += (f2){q2.x, q2.y} * a2 * T2;
-                    Cbd += (f2){q2.z, q2.w} * a2 * T2;
+                    // forward.cu:454-464: C += c * alpha * T per channel.  The weight alpha * T is formed
+                    // once and each pair of channels is one packed fused multiply-add (the sums are
+                    // compared at 1e-5 absolute, no integer output depends on them): 5 instructions where
+                    // the reference's order of operations takes 12.
+                    const float wgt = alpha * T;
+                    const f2 w2 = {wgt, wgt};
+                    Crg = __builtin_elementwise_fma((f2){q2.x, q2.y}, w2, Crg);
+                    Cbd = __builtin_elementwise_fma((f2){q2.z, q2.w}, w2, Cbd);
                     if (DIM == 4) {
                         const float4 q3 = s_q3[j];
-                        R01 += (f2){q3.x, q3.y} * a2 * T2;
-                        R23 += (f2){q3.z, q3.w} * a2 * T2;
+                        R01 = __builtin_elementwise_fma((f2){q3.x, q3.y}, w2, R01);
+                        R23 = __builtin_elementwise_fma((f2){q3.z, q3.w}, w2, R23);
                     }
                     T = test_T;
                     last = (uint32_t)(base + j + 1);
