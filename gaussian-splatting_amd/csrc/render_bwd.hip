@@ -84,8 +84,10 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
 
     float accum_S = 0.f, last_S = 0.f, last_alpha = 0.f;
 
-    const float ddelx_dx = 0.5f * a.W;
-    const float ddely_dy = 0.5f * a.H;
+    // constant factor of gradient component (tid & 15), applied once per (tile, instance) sum:
+    // ddelx_dx = W/2 and ddely_dy = H/2 (backward.cu:568-569) and the -0.5 of the conic terms
+    const int comp_id = tid & 15;
+    const float scale = comp_id == 0 ? -0.5f * a.W : comp_id == 1 ? -0.5f * a.H : comp_id <= 4 ? -0.5f : 1.0f;
 
     // number of list entries any pixel of this tile needs
     {
@@ -188,17 +190,19 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
             last_alpha = alpha_e;
             dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
 
+            // backward.cu:669-684 with the constant factors taken out of the per-pixel terms: with
+            // GL = G * dL/dG (= opacity * G * dL/dalpha), h = GL * dx, k = GL * dy the reference's
+            //   dL/dmean2D = -(h * conic.x + k * conic.y) * W/2,  -(k * conic.z + h * conic.y) * H/2
+            //   dL/dconic  = -0.5 * (h * dx, h * dy, k * dy)
+            // and the factors -W/2, -H/2, -0.5 multiply the sums when they leave LDS (`scale` below).
             const float g_op = G_e * dL_dalpha;
-            const float dL_dG = co.w * dL_dalpha;
-            const float gdx = G_e * dx;
-            const float gdy = G_e * dy;
-            const float dG_ddelx = -gdx * co.x - gdy * co.y;
-            const float dG_ddely = -gdy * co.z - gdx * co.y;
-            const float g_mx = dL_dG * dG_ddelx * ddelx_dx;
-            const float g_my = dL_dG * dG_ddely * ddely_dy;
-            const float g_cx = -0.5f * gdx * dx * dL_dG;
-            const float g_cy = -0.5f * gdx * dy * dL_dG;
-            const float g_cw = -0.5f * gdy * dy * dL_dG;
+            const float GL = co.w * g_op;
+            const float h = GL * dx, k = GL * dy;
+            const float g_mx = fmaf(k, co.y, h * co.x);
+            const float g_my = fmaf(h, co.y, k * co.z);
+            const float g_cx = h * dx;
+            const float g_cy = h * dy;
+            const float g_cw = k * dy;
 
             // 16 gradient components x 64 pixels -> 16 sums: transpose-reduce inside each
             // row of 16 lanes, fold the four rows with two lane swaps, then 16 lanes add
@@ -214,7 +218,7 @@ const float tot = rows_sum4(row_transpose_sum16(comp, lane));
         for (int h = 0; h < BWD_BATCH / 16; ++h) {
             const int j = (tid >> 4) + 16 * h;
             if (j >= nb) break;
-            const float v = s_acc[j][tid & 15];
+            const float v = s_acc[j][tid & 15] * scale;
             if (v != 0.0f) atomicAdd(a.acc + (size_t)__float_as_uint(s_q1[j].w) * 16 + (tid & 15), v);
         }
     }
