@@ -81,6 +81,9 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
     bg_dot_dpixel += a.bg[0] * D01.x;
     bg_dot_dpixel += a.bg[1] * D01.y;
     bg_dot_dpixel += a.bg[2] * D2i.x;
+    // backward.cu:664-667: the background's share of dL/dalpha is -T_final / (1 - alpha) * (bg . dL/dpixel);
+    // the part that does not depend on the Gaussian is formed once per pixel
+    const float bg_term = -T_final * bg_dot_dpixel;
 
     float accum_S = 0.f, last_S = 0.f, last_alpha = 0.f;
 
@@ -122,7 +125,7 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
         }
         __syncthreads();
 
-#pragma unroll 1
+#pragma unroll 1   // unrolling 2x / 4x changes nothing measurable
         for (int j = 0; j < nb; ++j) {
             const uint32_t contributor = (uint32_t)(max_last - 1 - base - j);
             const float4 q0 = s_q0[j];
@@ -185,10 +188,8 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
             const float S = S2.x + S2.y;
             accum_S = fmaf(last_alpha, last_S - accum_S, accum_S);
             last_S = S;
-            float dL_dalpha = S - accum_S;
-            dL_dalpha *= T;
             last_alpha = alpha_e;
-            dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
+            const float dL_dalpha = fmaf(bg_term, inv_1ma, (S - accum_S) * T);
 
             // backward.cu:669-684 with the constant factors taken out of the per-pixel terms: with
             // GL = G * dL/dG (= opacity * G * dL/dalpha), h = GL * dx, k = GL * dy the reference's
