@@ -61,42 +61,53 @@ __device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t v) {
     return v;
 }
 
-// Lane exchanges inside a row of 16 lanes (DPP, no LDS): value of lane ^ 1, ^ 2, ^ 4, ^ 8.
+// Lane exchanges inside a quad (DPP, no LDS): value of lane ^ 1, ^ 2.
 __device__ __forceinline__ float lane_xor1(float v) { return dpp_f<0xB1, 0xf>(v); }   // quad_perm [1,0,3,2]
 __device__ __forceinline__ float lane_xor2(float v) { return dpp_f<0x4E, 0xf>(v); }   // quad_perm [2,3,0,1]
-__device__ __forceinline__ float lane_xor8(float v) { return dpp_f<0x128, 0xf>(v); }  // row_ror:8
-__device__ __forceinline__ float lane_xor4(float v) {
-    const int x = __builtin_bit_cast(int, v);
-    int t = __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xA, false);  // row_shr:4 into lanes 4-7, 12-15
-    t = __builtin_amdgcn_update_dpp(t, x, 0x104, 0xf, 0x5, false);      // row_shl:4 into lanes 0-3, 8-11
-    return __builtin_bit_cast(float, t);
+
+// Transposing reduction of 16 per-lane values over the wave: on return every lane holds the sum over
+// all 64 lanes of v[wave_transpose_slot(lane)].  Each fold halves the number of live registers: of a
+// pair of values a lane keeps the one that one of its lane bits selects and adds the partner lane's
+// copy of it.  The two big folds (8 and 4 pairs) use lane bits 3 and 2, which are *bank* bits of the
+// DPP control (a bank is four lanes): a v_add_f32_dpp restricted by bank_mask writes only the lanes
+// that keep that value, so a pair folds in two instructions with no select.  The two small folds go
+// across the rows of 16 lanes (lane bits 5 and 4): v_permlane32_swap / v_permlane16_swap put the
+// halves (the odd and even rows) of two registers side by side, so one swap and one add fold a pair.
+// What is left is one register whose four lanes of a quad hold partial sums of the same value: two
+// plain DPP adds.  26 DPP adds, 3 swaps and 3 adds in all, where a value-by-value reduction of 16
+// values needs 96 DPP adds.  The asm blocks start with the wait states a DPP read of a just-written
+// VGPR needs (the compiler does not see inside them).
+__device__ __forceinline__ int wave_transpose_slot(int lane) {
+    return ((lane >> 4) & 1) * 8 + ((lane >> 5) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1);
 }
 
-// Transposing reduction of 16 per-lane values over a row of 16 lanes: on return
-// lane l holds the sum over its row of v[l & 15].  Each butterfly step halves
-// the number of live registers: a lane keeps the half whose index bit matches
-// one of its lane bits and adds the partner lane's copy.  The two big steps use
-// lane bits 3 and 2, which are *bank* bits of the DPP control (a bank is four
-// lanes): a v_add_f32_dpp restricted by bank_mask writes only the lanes that
-// keep that half, so a pair of values folds in two instructions with no select.
-// The two small steps (lane bits 1 and 0, inside a bank) select and add.
-// 33 instructions in all, where a value-by-value reduction needs 64.
-// The asm blocks start with the wait states a DPP read of a just-written VGPR
-// needs (the compiler does not see inside them).
-__device__ __forceinline__ float row_transpose_sum16(const float (&v)[16], int lane) {
-    // lane bit 3 picks index bit 0, bit 2 picks bit 1, bit 1 picks bit 2, bit 0 picks bit 3:
-    // feed the values in bit-reversed order so that lane l ends up with v[l].
-    float a[8], b[4], c[2];
+// N: 16, or 14 when v[14] and v[15] are zero (their fold is skipped).
+template <int N = 16>
+__device__ __forceinline__ float wave_transpose_sum16(const float (&v)[16]) {
+    static_assert(N == 16 || N == 14, "16 values, or 14 and two zeros");
+    float a[8], b[4];
+    // a[k] = lane bit 3 ? v[2k + 1] : v[2k], summed over lane bit 3
 #define GS_FOLD3(i, lo, hi) \
     "v_add_f32_dpp %" #i ", %" #lo ", %" #lo " row_ror:8 row_mask:0xf bank_mask:0x3\n\t" \
     "v_add_f32_dpp %" #i ", %" #hi ", %" #hi " row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-    asm("s_nop 1\n\t"
-        GS_FOLD3(0, 8, 9) GS_FOLD3(1, 10, 11) GS_FOLD3(2, 12, 13) GS_FOLD3(3, 14, 15)
-        GS_FOLD3(4, 16, 17) GS_FOLD3(5, 18, 19) GS_FOLD3(6, 20, 21) GS_FOLD3(7, 22, 23)
-        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
-        : "v"(v[0]), "v"(v[8]), "v"(v[4]), "v"(v[12]), "v"(v[2]), "v"(v[10]), "v"(v[6]), "v"(v[14]),
-          "v"(v[1]), "v"(v[9]), "v"(v[5]), "v"(v[13]), "v"(v[3]), "v"(v[11]), "v"(v[7]), "v"(v[15]));
+    if (N == 16) {
+        asm("s_nop 1\n\t"
+            GS_FOLD3(0, 8, 9) GS_FOLD3(1, 10, 11) GS_FOLD3(2, 12, 13) GS_FOLD3(3, 14, 15)
+            GS_FOLD3(4, 16, 17) GS_FOLD3(5, 18, 19) GS_FOLD3(6, 20, 21) GS_FOLD3(7, 22, 23)
+            : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
+            : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+              "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+    } else {
+        asm("s_nop 1\n\t"
+            GS_FOLD3(0, 7, 8) GS_FOLD3(1, 9, 10) GS_FOLD3(2, 11, 12) GS_FOLD3(3, 13, 14)
+            GS_FOLD3(4, 15, 16) GS_FOLD3(5, 17, 18) GS_FOLD3(6, 19, 20)
+            : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6])
+            : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+              "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]));
+        a[7] = 0.f;
+    }
 #undef GS_FOLD3
+    // b[i] = lane bit 2 ? a[2i + 1] : a[2i], summed over lane bit 2
 #define GS_FOLD2(i, lo, hi) \
     "v_add_f32_dpp %" #i ", %" #lo ", %" #lo " row_shl:4 row_mask:0xf bank_mask:0x5\n\t" \
     "v_add_f32_dpp %" #i ", %" #hi ", %" #hi " row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
@@ -105,10 +116,17 @@ __device__ __forceinline__ float row_transpose_sum16(const float (&v)[16], int l
         : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
         : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
 #undef GS_FOLD2
-    const bool b0 = lane & 1, b1 = lane & 2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) c[i] = (b1 ? b[2 * i + 1] : b[2 * i]) + lane_xor2(b1 ? b[2 * i] : b[2 * i + 1]);
-    return (b0 ? c[1] : c[0]) + lane_xor1(b0 ? c[0] : c[1]);
+    // lanes 0-31 keep b[2i], lanes 32-63 b[2i + 1], summed over lane bit 5
+    const auto h0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(b[0]), __float_as_uint(b[1]), false, false);
+    const auto h1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(b[2]), __float_as_uint(b[3]), false, false);
+    const float c0 = __uint_as_float(h0[0]) + __uint_as_float(h0[1]);
+    const float c1 = __uint_as_float(h1[0]) + __uint_as_float(h1[1]);
+    // even rows keep c0, odd rows c1, summed over lane bit 4
+    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(c0), __float_as_uint(c1), false, false);
+    float d = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+    d += lane_xor1(d);
+    d += lane_xor2(d);
+    return d;
 }
 
 // Lane masks.  A ballot of a direct comparison is one v_cmp into an SGPR pair, and a
@@ -189,20 +207,6 @@ constexpr int SH_ROW_F = 48;          // floats per row (M = 16)
 constexpr int SH_ROW_CHUNKS = 12;     // float4 per row
 constexpr int SH_LDS_STRIDE = 13;     // float4 per row in LDS
 constexpr int SH_WAVE_LDS_F4 = 64 * SH_LDS_STRIDE;
-
-// Sum over the four rows of 16 lanes: every lane gets v[l%16] + v[l%16+16] + v[l%16+32] + v[l%16+48].
-// v_permlane32_swap exchanges the upper half of its first operand with the lower
-// half of its second, v_permlane16_swap the odd rows of the first with the even
-// rows of the second; fed the same value twice, the two results hold the two
-// halves (rows) side by side, so one add folds them.
-__device__ __forceinline__ float rows_sum4(float v) {
-    const uint32_t u = __float_as_uint(v);
-    const auto h = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    const float s = __uint_as_float(h[0]) + __uint_as_float(h[1]);
-    const uint32_t us = __float_as_uint(s);
-    const auto q = __builtin_amdgcn_permlane16_swap(us, us, false, false);
-    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
-}
 
 // Orders one wave's LDS writes before its later LDS reads (other lanes' data).
 // The LDS unit serves a wave's instructions in order, so no hardware wait is

@@ -4,9 +4,10 @@
 // is walked back to front starting at the last instance any pixel of the tile
 // actually blended.  The reference issues up to 14 global float atomics per
 // (pixel, Gaussian) pair; here the 14 gradient components of an instance are
-// summed over the wave's 64 pixels by a transposing DPP butterfly (15 lane
-// exchanges) and two row swaps, over the four waves by LDS atomics (16 lanes,
-// 16 different words: an LDS atomic whose lanes share a word serialises), and
+// summed over the wave's 64 pixels by a transposing reduction (each fold halves
+// the live registers: 31 lane-exchanging instructions for all 14 sums), over
+// the four waves by LDS atomics (16 lanes, 16 different words: an LDS atomic
+// whose lanes share a word serialises), and
 // leave the workgroup once per (tile, instance) as a 64-byte GradRec update:
 // 16 lanes add to 16 consecutive floats, so one wave instruction carries four
 // complete line-half atomics instead of 64 scattered ones.
@@ -89,6 +90,7 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
 
     // constant factor of gradient component (tid & 15), applied once per (tile, instance) sum:
     // ddelx_dx = W/2 and ddely_dy = H/2 (backward.cu:568-569) and the -0.5 of the conic terms
+    const int acc_slot = wave_transpose_slot(lane);   // the component whose wave sum this lane ends up with
     const int comp_id = tid & 15;
     const float scale = comp_id == 0 ? -0.5f * a.W : comp_id == 1 ? -0.5f * a.H : comp_id <= 4 ? -0.5f : 1.0f;
 
@@ -205,13 +207,13 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
             const float g_cy = h * dy;
             const float g_cw = k * dy;
 
-            // 16 gradient components x 64 pixels -> 16 sums: transpose-reduce inside each
-            // row of 16 lanes, fold the four rows with two lane swaps, then 16 lanes add
-            // to 16 different LDS words (the four waves of the tile meet there).
+            // 16 gradient components x 64 pixels -> 16 sums by the transposing reduction over the
+            // wave; one lane of every quad then adds its sum to LDS, 16 lanes on 16 different words
+            // (the four waves of the tile meet there).
             const float comp[16] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_rg.x, g_rg.y, g_bd.x, g_bd.y,
                                     g_r01.x, g_r01.y, g_r23.x, g_r23.y, 0.f, 0.f};
-const float tot = rows_sum4(row_transpose_sum16(comp, lane));
-            if (lane < 16) atomicAdd(&s_acc[j][lane], tot);
+            const float tot = wave_transpose_sum16<14>(comp);
+            if ((lane & 3) == 0) atomicAdd(&s_acc[j][acc_slot], tot);
         }
         __syncthreads();
         // 16 lanes per instance: one 64-byte GradRec update

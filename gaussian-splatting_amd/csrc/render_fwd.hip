@@ -7,7 +7,7 @@
 // reads.  A wave whose 64 pixels are all saturated stops computing (ballot);
 // the workgroup stops when its four waves have.  The per-Gaussian statistics
 // of the fork (sum of transmittance and hit count, forward.cu:431-432) are
-// reduced over the wave 16 instances at a time by a transposing DPP butterfly,
+// reduced over the wave 16 instances at a time by a transposing reduction,
 // over the four waves through LDS, and leave the workgroup as one pair of
 // adjacent float atomics per instance.
 #include "kernels.h"
@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
     int last_g = -1;
 
     if (tid < 4) s_wdone[tid] = 0;
+    const int slot = wave_transpose_slot(lane);   // which of a group's 16 sums this lane ends up with
 
     for (int base = 0; base < total; base += TILE_PIX) {
         __syncthreads();
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
 
         // Instances in groups of 16: the transmittance a lane contributes to each instance's
         // statistic waits in a register and one transposing reduction per group sums all 16 over
-        // the wave (17 lane exchanges per group instead of 6 per instance).
+        // the wave (about 2 lane exchanges per instance instead of 6).
 #pragma unroll 1
         for (int j0 = 0; j0 < nb; j0 += 16) {
             if (live == 0) {  // nothing left for this wave: its share of the remaining statistics is zero
@@ -157,10 +158,10 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
                     last_g = (int)__float_as_uint(q1.w);
                 }
             }
-            const float tot = rows_sum4(row_transpose_sum16(tv, lane));
-            if (lane < 16) {
-                s_gsum[w][j0 + lane] = tot;
-                s_gcnt[w][j0 + lane] = (uint32_t)((((lane & 8) ? cnt_hi : cnt_lo) >> ((lane & 7) * 8)) & 0xffu);
+            const float tot = wave_transpose_sum16(tv);
+            if ((lane & 3) == 0) {   // one lane of every quad: the sum of instance j0 + slot
+                s_gsum[w][j0 + slot] = tot;
+                s_gcnt[w][j0 + slot] = (uint32_t)((((slot & 8) ? cnt_hi : cnt_lo) >> ((slot & 7) * 8)) & 0xffu);
             }
         }
         if (lane == 0) s_wdone[w] = live == 0 ? 1 : 0;
