@@ -197,12 +197,14 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
             // GL = G * dL/dG (= opacity * G * dL/dalpha), h = GL * dx, k = GL * dy the reference's
             //   dL/dmean2D = -(h * conic.x + k * conic.y) * W/2,  -(k * conic.z + h * conic.y) * H/2
             //   dL/dconic  = -0.5 * (h * dx, h * dy, k * dy)
-            // and the factors -W/2, -H/2, -0.5 multiply the sums when they leave LDS (`scale` below).
+            // The conic is the same for every pixel, so h and k are what is summed over the pixels;
+            // the combination with the conic and the factors -W/2, -H/2, -0.5 are applied to the sums
+            // when they leave LDS.
             const float g_op = G_e * dL_dalpha;
             const float GL = co.w * g_op;
             const float h = GL * dx, k = GL * dy;
-            const float g_mx = fmaf(k, co.y, h * co.x);
-            const float g_my = fmaf(h, co.y, k * co.z);
+            const float g_mx = h;
+            const float g_my = k;
             const float g_cx = h * dx;
             const float g_cy = h * dy;
             const float g_cw = k * dy;
@@ -221,7 +223,13 @@ __global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArg
         for (int h = 0; h < BWD_BATCH / 16; ++h) {
             const int j = (tid >> 4) + 16 * h;
             if (j >= nb) break;
-            const float v = s_acc[j][tid & 15] * scale;
+            float v = s_acc[j][comp_id];
+            if (comp_id < 2) {   // sums of h and k -> dL/dmean2D
+                const float other = s_acc[j][comp_id ^ 1];
+                const float4 q0 = s_q0[j];
+                v = (comp_id == 0 ? q0.z : q0.w) * v + s_q1[j].x * other;
+            }
+            v *= scale;
             if (v != 0.0f) atomicAdd(a.acc + (size_t)__float_as_uint(s_q1[j].w) * 16 + (tid & 15), v);
         }
     }
