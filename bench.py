@@ -275,10 +275,14 @@ def roofline_entry(dom, ent, achieved_hbm, ab, traffic, ms):
                  "ms_per_launch": ms, "limited_by": BOUND.get(dom)}, **hbm)
 
 
-def load_pmc_valu(P, W, H):
+def pmc_file(scene):
+    return os.path.join(ROOT, "profiles", "pmc_traffic.json" if scene == "street" else f"pmc_traffic_{scene}.json")
+
+
+def load_pmc_valu(P, W, H, scene="street"):
     """Per kernel: wave64 vector instructions per launch, LDS atomics per launch and the shader clock, from
     the committed PMC summary of this command (empty if none matches the workload)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    path = pmc_file(scene)
     try:
         with open(path) as f:
             d = json.load(f)
@@ -289,10 +293,10 @@ def load_pmc_valu(P, W, H):
         return {}
 
 
-def load_pmc_traffic(P, W, H):
+def load_pmc_traffic(P, W, H, scene="street"):
     """HBM bytes per launch from the rocprofv3 --pmc passes of this command, if a summary was
     committed for this workload (the counters cannot be read from inside the process)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    path = pmc_file(scene)
     try:
         with open(path) as f:
             d = json.load(f)
@@ -732,7 +736,7 @@ def main():
             extras["translucent"] = {"error": repr(ex)}
 
     if rank == 0:
-        traffic = load_pmc_traffic(P, W, H)
+        traffic = load_pmc_traffic(P, W, H, args.scene)
         per_kernel = {}
         launches = lambda k: 1 if k in KernelTimer.PER_STEP else V          # per step
 
@@ -755,9 +759,9 @@ def main():
         # Vector-instruction issue: wave64 instructions a launch executes (SQ_INSTS_VALU of the committed PMC passes
         # of this command) over the live duration, against 1024 SIMDs x 0.5 instructions per clock (a wave64
         # instruction issues over 2 cycles on a 32-lane SIMD) at the clock the counters show.
-        valu = load_pmc_valu(P, W, H)
+        valu = load_pmc_valu(P, W, H, args.scene)
         for k, ent in per_kernel.items():
-            if k in valu and args.scene == "street":
+            if k in valu:
                 v = valu[k]
                 clk = min(v.get("clock_GHz") or 2.4, 2.4)   # short kernels: the busy counter runs past the kernel
                 peak = 1024 * 0.5 * clk      # G wave-instructions / s

@@ -114,7 +114,8 @@ def main():
         valu[k] = ent
     out_d["_valu"] = valu
     # bench.py defaults, which tools/collect_pmc.sh runs; another scene's file is never bench.py's default one
-    out_d["_workload"] = [6000000, 1920, 1080] if traffic_json == "pmc_traffic.json" else traffic_json
+    out_d["_workload"] = [6000000, 1920, 1080]
+    out_d["_scene"] = "street" if traffic_json == "pmc_traffic.json" else traffic_json[len("pmc_traffic_"):-len(".json")]
     out_d["_note"] = "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB, mean over the launches of the PMC passes"
     with open(os.path.join(ROOT, "profiles", traffic_json), "w") as f:
         json.dump(out_d, f, indent=1)
