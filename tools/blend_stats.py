@@ -48,6 +48,7 @@ def main():
     tiles = rng.choice(gx * gy, size=min(nsample, gx * gy), replace=False)
     tot = dict(walked=0, quad_visits=0, quad_hit=0, rows_exact=0, rows_box=0, rows_exact_sum=0, rows_box_sum=0,
                fwd_walked=0, fwd_quad_hit=0, fwd_rows_exact=0, pairs_hit=0)
+    hist = torch.zeros(16, dtype=torch.int64)
     py, px = torch.meshgrid(torch.arange(16, device=dev), torch.arange(16, device=dev), indexing="ij")
     blk = ((py // 4) * 4 + (px // 4)).reshape(-1)                    # 4x4 block of every pixel of the tile
     quad = ((py // 8) * 2 + (px // 8)).reshape(-1)
@@ -82,6 +83,10 @@ def main():
         for q in range(4):
             qh[:, q] = hit[:, quad == q].any(1)
         tot["quad_hit"] += int(qh.sum())
+        for q in range(4):   # how many of a quadrant's 64 pixels a blending visit blends
+            cq = hit[:, quad == q].sum(1)
+            cq = cq[cq > 0]
+            hist += torch.bincount(torch.clamp((cq - 1) // 4, max=15), minlength=16).cpu()
         # rows: per block, the instances that can reach it and that one of its pixels still needs
         blk_last = torch.zeros(16, dtype=torch.int64, device=dev)
         need_exact = torch.zeros((Lw, 16), dtype=torch.bool, device=dev)
@@ -119,6 +124,8 @@ def main():
           (s["rows_exact_sum"], s["rows_exact_sum"] / s["walked"]))
     print("  row scheme, box reach:   wave visits     ", s["rows_box"], " (block visits %d, %.2f blocks per instance)" %
           (s["rows_box_sum"], s["rows_box_sum"] / s["walked"]))
+    print("  pixels blended per blending quadrant visit, share of visits by 1-4, 5-8, ..., 61-64:",
+          " ".join("%.3f" % (float(h) / max(1, int(hist.sum()))) for h in hist))
     full, skip = 160.0, 20.0
     now = s["quad_hit"] * full + (s["quad_visits"] - s["quad_hit"]) * skip
     print("  instruction estimate (160 per blending visit, 20 per skipped one): now %.3g, rows exact %.3g (%.2fx), rows box %.3g (%.2fx)" %
