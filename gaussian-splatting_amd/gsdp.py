@@ -69,6 +69,7 @@ class GradReducer:
         self.dense_streak = 0
         self.plans = 0
         self.last_union = None      # (rows in the union, rows) of the last probe
+        self.mask_as_bytes = True   # the row masks travel as uint8 with MAX (else as int32 with SUM)
 
     def _active(self):
         return dist.is_initialized() and dist.get_world_size(self.group) > 1
@@ -134,8 +135,16 @@ class GradReducer:
         union = touched if touched.dtype == torch.uint8 else touched.ne(0).to(torch.uint8)
         if dist.get_backend(self.group) == "gloo" and union.is_cuda:
             self._staged(union, dist.ReduceOp.MAX)
-        else:
-            dist.all_reduce(union, op=dist.ReduceOp.MAX, group=self.group)
+        elif self.mask_as_bytes:
+            try:
+                dist.all_reduce(union, op=dist.ReduceOp.MAX, group=self.group)
+            except (RuntimeError, ValueError, TypeError, NotImplementedError):
+                # a backend without 8-bit MAX refuses the call on every rank alike, before anything is sent
+                self.mask_as_bytes = False
+        if not self.mask_as_bytes:
+            wide = union.to(torch.int32)
+            dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=self.group)
+            union = wide
         rows = torch.nonzero(union).view(-1)            # host-synchronous: the size of the exchange
         self.last_union = (int(rows.numel()), int(union.numel()))
         if self.sparse == "auto" and rows.numel() > self.sparse_below * union.numel():

@@ -214,7 +214,7 @@ def _sparse_worker(rank, world, port, out_dir):
     params, _ = _sink_problem()
     out = {}
     for name, density, mode in (("sparse_auto", 0.03, "auto"), ("dense_auto", 0.6, "auto"), ("dense_forced_sparse", 0.6, "always"),
-                                ("never", 0.03, "never"), ("nothing_touched", 0.0, "auto")):
+                                ("never", 0.03, "never"), ("nothing_touched", 0.0, "auto"), ("sparse_wide_mask", 0.03, "auto")):
         views = _sparse_views(1000, 5, density)
         sink, leaves = _make_fake_sink(params)
         sink.begin_step()
@@ -224,6 +224,8 @@ def _sparse_worker(rank, world, port, out_dir):
                                      dL_dmeans2D=torch.ones(3)))
             sink.hit_counts.append(views[vi].ne(0).to(torch.int32))   # what the forward's gauss_count says
         red = gsdp.GradReducer(sparse=mode)
+        if name == "sparse_wide_mask":
+            red.mask_as_bytes = False     # the row masks as int32 with SUM, for backends without 8-bit MAX
         took = gsdp.reduce_flush(sink, red, chunks=3)
         out[name] = dict(grads=[p.grad.clone() for p in leaves], took=took, union=red.last_union,
                          launches=len(sink.launches))
@@ -251,7 +253,7 @@ def test_sparse_row_exchange_world2(tmp_path):
     params, _ = _sink_problem()
     order = ("xyz", "dc", "rest", "opacity", "scaling", "rotation", "reps")
     expect = dict(sparse_auto=("sparse", 0.03), dense_auto=("dense", 0.6), dense_forced_sparse=("sparse", 0.6),
-                  never=("dense", 0.03), nothing_touched=("sparse", 0.0))
+                  never=("dense", 0.03), nothing_touched=("sparse", 0.0), sparse_wide_mask=("sparse", 0.03))
     for r in range(world):
         got = torch.load(os.path.join(tmp_path, f"p{r}.pt"), weights_only=True)
         for name, (took, density) in expect.items():
