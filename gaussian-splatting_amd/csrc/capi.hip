@@ -370,7 +370,7 @@ int gsr_layout(int P, int W, int H, int64_t R, GsrLayout* out) {
     const GeomBuf g = geom_buf(z, (size_t)P);
     out->rec = (char*)g.rec - z;
     out->cov3D = (char*)g.cov3D - z;
-    out->tiles = (char*)g.bin - z;
+    out->tiles = (char*)g.rect - z;
     out->clamped = (char*)g.clamped - z;
     out->block_sums = (char*)g.block_sums - z;
     out->total = (char*)g.total - z;

@@ -30,7 +30,8 @@ struct PreArgs {
     float* out_depths;
     SplatRec* rec;
     float* cov3D;
-    uint4* bin;
+    uint2* rect;
+    uint2* dt;
     GStat* gstat;
     uint8_t* clamped;
     uint32_t* block_sums;
@@ -152,7 +153,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs
             bin.w = tiles;
         }
         a.radii[idx] = radius;
-        a.bin[idx] = bin;
+        a.rect[idx] = make_uint2(bin.x, bin.y);
+        a.dt[idx] = make_uint2(bin.z, bin.w);
         a.gstat[idx] = GStat{0.0f, 0u};
     }
     // tiles touched by this block of 256 Gaussians
@@ -190,7 +192,8 @@ struct FwdBatchView {
     int* radii;
     float* out_depths;
     SplatRec* rec;
-    uint4* bin;
+    uint2* rect;
+    uint2* dt;
     GStat* gstat;
     uint8_t* clamped;
     uint32_t* block_sums;
@@ -307,7 +310,8 @@ __global__ void __launch_bounds__(PRE_BLOCK, PRE_FWD_BATCH_WAVES) preprocess_fwd
                 }
             }
             bv.radii[i] = radius;
-            bv.bin[i] = bin;
+            bv.rect[i] = make_uint2(bin.x, bin.y);
+            bv.dt[i] = make_uint2(bin.z, bin.w);
             bv.gstat[i] = GStat{0.0f, 0u};
         }
         const uint32_t ws = wave_sum_u32(tiles);
@@ -413,30 +417,30 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* sum
 // Depth keys for ordering the Gaussians front to back: the f32 bits of the
 // view-space depth (positive floats order like their bit patterns), all ones
 // for Gaussians that produce no instance so that they sort to the end.
-__global__ void __launch_bounds__(PRE_BLOCK) depth_keys_kernel(int P, const uint4* bin, const uint32_t* vis_off,
+__global__ void __launch_bounds__(PRE_BLOCK) depth_keys_kernel(int P, const uint2* dt, const uint32_t* vis_off,
                                                                uint32_t* keys, uint32_t* vals) {
     // vis_off == null: one pair per Gaussian (those without instances get the largest key).
     // Otherwise only Gaussians with instances get a pair, packed in index order: a block's pairs
     // start at vis_off[block] (blocks = the preprocess blocks that counted them).
     __shared__ uint32_t s_w[4];
     const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
-    const uint4 b = i < P ? bin[i] : make_uint4(0, 0, 0, 0);
+    const uint2 b = i < P ? dt[i] : make_uint2(0, 0);   // depth bits, tiles
     if (!vis_off) {
         if (i < P) {
-            keys[i] = b.w ? b.z : 0xFFFFFFFFu;
+            keys[i] = b.y ? b.x : 0xFFFFFFFFu;
             vals[i] = (uint32_t)i;
         }
         return;
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint64_t m = __ballot(b.w > 0);
+    const uint64_t m = __ballot(b.y > 0);
     if (lane == 0) s_w[w] = (uint32_t)__popcll(m);
     __syncthreads();
     uint32_t base = vis_off[blockIdx.x];
     for (int k = 0; k < w; ++k) base += s_w[k];
-    if (b.w > 0) {
+    if (b.y > 0) {
         const uint32_t dst = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        keys[dst] = b.z;
+        keys[dst] = b.x;
         vals[dst] = (uint32_t)i;
     }
 }
@@ -444,16 +448,16 @@ __global__ void __launch_bounds__(PRE_BLOCK) depth_keys_kernel(int P, const uint
 // The tile rectangles in depth order: sbin[i] = {rect origin, rect size, Gaussian
 // index, tiles} of the i-th Gaussian front to back (the one random gather of the
 // emission), and the tiles touched per block of 256 of them.
-__global__ void __launch_bounds__(PRE_BLOCK) order_gather_kernel(int P, const uint32_t* order, const uint4* bin,
+__global__ void __launch_bounds__(PRE_BLOCK) order_gather_kernel(int P, const uint32_t* order, const uint2* rect,
                                                                  uint4* sbin, uint32_t* sums) {
     __shared__ uint32_t s_tmp[4];
     const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
     uint32_t t = 0;
     if (i < P) {
         const uint32_t gid = order[i];
-        const uint4 b = bin[gid];
-        sbin[i] = make_uint4(b.x, b.y, gid, b.w);
-        t = b.w;
+        const uint2 r = rect[gid];                      // 8 bytes per random access
+        t = (r.y & 0xffffu) * (r.y >> 16);              // tiles = width * height
+        sbin[i] = make_uint4(r.x, r.y, gid, t);
     }
     const uint32_t ws = wave_sum_u32(t);
     if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = ws;
@@ -507,7 +511,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) emit_keys_kernel(int P, int grid_x,
 // the other two); the two-dimensional prefix sum of the marks is the cover count per tile, the
 // running sum of the counts in tile order gives the ranges that identifyTileRanges
 // (rasterizer_impl.cu:115-137) finds by scanning the sorted keys, and the counts summed per
-// digit are the histograms the radix passes start from.  Per view this reads 16 bytes per
+// digit are the histograms the radix passes start from.  Per view this reads 8 bytes per
 // Gaussian instead of two sweeps over the instances (histogram and range scan).
 constexpr int TC_THREADS = 1024;
 constexpr int TC_BLOCKS = 256;
@@ -523,7 +527,7 @@ bool tile_counts_fit(int W, int H, int passes) {
     return tile_finish_lds(gx, gy, passes) <= TILE_LDS_LIMIT;
 }
 
-__global__ void __launch_bounds__(TC_THREADS) tile_count_kernel(int P, const uint4* __restrict__ bin, int gx, int gy,
+__global__ void __launch_bounds__(TC_THREADS) tile_count_kernel(int P, const uint2* __restrict__ rect, int gx, int gy,
                                                                int* __restrict__ diff) {
     extern __shared__ int s_diff[];
     const int nd = (gx + 1) * (gy + 1), pitch = gx + 1;
@@ -532,15 +536,15 @@ __global__ void __launch_bounds__(TC_THREADS) tile_count_kernel(int P, const uin
     // four independent loads in flight per lane: the loop is bound by their latency
     const int stride = gridDim.x * TC_THREADS;
     for (int i0 = blockIdx.x * TC_THREADS + threadIdx.x; i0 < P; i0 += 4 * stride) {
-        uint4 b[4];
+        uint2 b[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u * stride;
-            b[u] = i < P ? bin[i] : make_uint4(0, 0, 0, 0);
+            b[u] = i < P ? rect[i] : make_uint2(0, 0);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (b[u].w == 0) continue;
+            if (b[u].y == 0) continue;   // no instances: a rendered Gaussian's rectangle has width and height > 0
             const int x0 = (int)(b[u].x & 0xffffu), y0 = (int)(b[u].x >> 16);
             const int x1 = x0 + (int)(b[u].y & 0xffffu), y1 = y0 + (int)(b[u].y >> 16);
             atomicAdd(&s_diff[y0 * pitch + x0], 1);
@@ -671,7 +675,7 @@ hipError_t launch_tile_ranges_from_rects(const GeomBuf& g, int P, int W, int H, 
                             (int)lds_f);
     if (e != hipSuccess) return e;
     const int blocks = min(TC_BLOCKS, (P + TC_THREADS - 1) / TC_THREADS);
-    hipLaunchKernelGGL(tile_count_kernel, dim3(blocks), dim3(TC_THREADS), lds_c, st, P, g.bin, gx, gy, im.tile_diff);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(blocks), dim3(TC_THREADS), lds_c, st, P, g.rect, gx, gy, im.tile_diff);
     hipLaunchKernelGGL(tile_finish_kernel, dim3(1), dim3(TF_THREADS), lds_f, st, gx, gy, im.tile_diff, im.ranges, ghist,
                        passes, nbits, lowbits, seg_start ? 1 << (nbits - lowbits) : 0, seg_start, seg_tile0);
     return hipGetLastError();
@@ -697,10 +701,10 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* keys, 
 // The reference's 64-bit sort keys, rebuilt from the sorted tile ids and the
 // depth of each instance's Gaussian (for inspection and tests).
 __global__ void __launch_bounds__(256) keys64_kernel(const uint32_t* tile_keys, const uint32_t* point_list,
-                                                     const uint4* bin, int64_t R, uint64_t* out) {
+                                                     const uint2* dt, int64_t R, uint64_t* out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= R) return;
-    out[i] = ((uint64_t)tile_keys[i] << 32) | bin[point_list[i]].z;
+    out[i] = ((uint64_t)tile_keys[i] << 32) | dt[point_list[i]].x;
 }
 
 // Also the last kernel of a forward pass: it hands the sort's error word to the caller's host word
@@ -740,7 +744,7 @@ hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, cons
     a.raw = s.raw_params; a.shs_rest = s.shs_rest;
     a.cam.view = s.viewmatrix; a.cam.proj = s.projmatrix; a.cam.campos = s.campos;
     a.radii = o.radii; a.out_depths = o.out_depths;
-    a.rec = g.rec; a.cov3D = g.cov3D; a.bin = g.bin; a.gstat = g.gstat; a.clamped = g.clamped;
+    a.rec = g.rec; a.cov3D = g.cov3D; a.rect = g.rect; a.dt = g.dt; a.gstat = g.gstat; a.clamped = g.clamped;
     a.block_sums = g.block_sums;
     a.vis_sums = g.vis_sums;
     const int nb = (s.P + PRE_BLOCK - 1) / PRE_BLOCK;
@@ -768,7 +772,7 @@ hipError_t launch_preprocess_fwd_batch(const GsrScene& s, int nviews, const GsrF
             bv.cam.view = fv.viewmatrix; bv.cam.proj = fv.projmatrix; bv.cam.campos = fv.campos;
             bv.tanx = fv.tanfovx; bv.tany = fv.tanfovy; bv.W = fv.W; bv.H = fv.H; bv.aa = fv.antialiasing;
             bv.radii = fv.radii; bv.out_depths = fv.out_depths;
-            bv.rec = g.rec; bv.bin = g.bin; bv.gstat = g.gstat; bv.clamped = g.clamped;
+            bv.rec = g.rec; bv.rect = g.rect; bv.dt = g.dt; bv.gstat = g.gstat; bv.clamped = g.clamped;
             bv.block_sums = g.block_sums; bv.vis_sums = g.vis_sums;
         }
         hipLaunchKernelGGL(preprocess_fwd_batch_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, b);
@@ -788,7 +792,7 @@ hipError_t launch_scan_u32(uint32_t* sums, int nb, uint64_t* total, hipStream_t 
 }
 
 hipError_t launch_depth_order(const GeomBuf& g, int P, int n, hipStream_t st, int* order_buffer) {
-    hipLaunchKernelGGL(depth_keys_kernel, dim3((P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, st, P, g.bin,
+    hipLaunchKernelGGL(depth_keys_kernel, dim3((P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, st, P, g.dt,
                        n < P ? g.vis_sums : (const uint32_t*)nullptr, g.dkeys[0], g.dvals[0]);
     uint32_t* k[2] = {g.dkeys[0], g.dkeys[1]};
     uint32_t* v[2] = {g.dvals[0], g.dvals[1]};
@@ -797,7 +801,7 @@ hipError_t launch_depth_order(const GeomBuf& g, int P, int n, hipStream_t st, in
 
 hipError_t launch_order_gather(const GeomBuf& g, const uint32_t* order, int n, hipStream_t st) {
     const int nb = (n + PRE_BLOCK - 1) / PRE_BLOCK;
-    hipLaunchKernelGGL(order_gather_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, n, order, g.bin, g.sbin, g.order_sums);
+    hipLaunchKernelGGL(order_gather_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, n, order, g.rect, g.sbin, g.order_sums);
     return hipGetLastError();
 }
 
@@ -805,7 +809,7 @@ hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, const uint32_t*
                             uint32_t* vals, hipStream_t st) {
     const int nb = (n + PRE_BLOCK - 1) / PRE_BLOCK;
     const int grid_x = (s.W + TILE_X - 1) / TILE_X;
-    hipLaunchKernelGGL(order_gather_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, n, order, g.bin, g.sbin, g.order_sums);
+    hipLaunchKernelGGL(order_gather_kernel, dim3(nb), dim3(PRE_BLOCK), 0, st, n, order, g.rect, g.sbin, g.order_sums);
     // total[0..1] were read by the host already; the scan rewrites the same values
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, g.order_sums, (uint32_t*)nullptr, nb,
                        g.total);
@@ -824,7 +828,7 @@ hipError_t launch_tile_ranges(const uint32_t* keys, int64_t R, uint2* ranges, in
 hipError_t launch_keys64(const GeomBuf& g, const uint32_t* tile_keys, const uint32_t* point_list, int64_t R,
                          uint64_t* out, hipStream_t st) {
     if (R <= 0) return hipSuccess;
-    hipLaunchKernelGGL(keys64_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, tile_keys, point_list, g.bin,
+    hipLaunchKernelGGL(keys64_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, tile_keys, point_list, g.dt,
                        R, out);
     return hipGetLastError();
 }

@@ -13,7 +13,9 @@ namespace gs {
 struct GeomBuf {
     SplatRec* rec;        // [P]
     float* cov3D;         // [P,6]
-    uint4* bin;           // [P] {x0 | y0<<16, w | h<<16, depth bits, tiles}
+    uint2* rect;          // [P] {x0 | y0<<16, w | h<<16} in tiles; zero for a Gaussian without instances
+    uint2* dt;            // [P] {depth bits, tiles}, directly behind rect (the kernels that need one of the
+                          //     two read 8 bytes per Gaussian instead of 16)
     GStat* gstat;         // [P] (sum of T, hit count), accumulated by the forward blend
     uint8_t* clamped;     // [P]
     uint32_t* block_sums; // [nblocks+1] tiles per block of 256 Gaussians in index order (gives the total)
@@ -35,7 +37,8 @@ inline GeomBuf geom_buf(const void* base, size_t P) {
     auto take = [&](size_t n) { char* q = p ? p + off : nullptr; off = align_up(off + n, 256); return q; };
     v.rec = (SplatRec*)take(P * sizeof(SplatRec));
     v.cov3D = (float*)take(P * 6 * sizeof(float));
-    v.bin = (uint4*)take(P * sizeof(uint4));
+    v.rect = (uint2*)take(2 * P * sizeof(uint2));
+    v.dt = v.rect ? v.rect + P : nullptr;
     v.gstat = (GStat*)take(P * sizeof(GStat));
     v.clamped = (uint8_t*)take(P);
     v.block_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));

@@ -47,7 +47,9 @@ def read_internals(out, P, W, H):
     res = {}
     res["rec"] = geom[lay.rec:lay.rec + P * 64].view(np.float32).reshape(P, 16)
     res["cov3D"] = geom[lay.cov3D:lay.cov3D + P * 24].view(np.float32).reshape(P, 6)
-    res["bin"] = geom[lay.tiles:lay.tiles + P * 16].view(np.uint32).reshape(P, 4)
+    # {x0 | y0<<16, w | h<<16} of every Gaussian, followed by {depth bits, tiles} of every Gaussian
+    res["bin"] = np.hstack([geom[lay.tiles:lay.tiles + P * 8].view(np.uint32).reshape(P, 2),
+                            geom[lay.tiles + P * 8:lay.tiles + P * 16].view(np.uint32).reshape(P, 2)])
     res["clamped"] = geom[lay.clamped:lay.clamped + P]
     res["final_T"] = img[lay.final_T:lay.final_T + W * H * 4].view(np.float32)
     res["n_contrib"] = img[lay.n_contrib:lay.n_contrib + W * H * 4].view(np.uint32)
