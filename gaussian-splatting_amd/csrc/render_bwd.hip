@@ -35,12 +35,13 @@ __device__ __forceinline__ int xcd_remap_b(int b, int n) {
 }
 
 // Instances staged per round.  128 rather than 256 keeps the workgroup at 16 KiB of LDS, so the
-// occupancy is set by the registers (6 waves per SIMD) and not by LDS (4); the kernel is bound by
-// the latency of each wave's instruction stream and gains from every extra wave.
+// occupancy is set by the registers (8 waves per SIMD) and not by LDS (4).
 constexpr int BWD_BATCH = 128;
 
 template <int DIM, bool INVD>
-__global__ void __launch_bounds__(TILE_PIX) render_bwd_kernel(const RenderBwdArgs a) {
+// 8 waves per SIMD: the register allocator gets 64 VGPRs (it takes 66 when left alone, which costs a wave).
+__global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(8, 8)))
+render_bwd_kernel(const RenderBwdArgs a) {
     // same regrouping of the SplatRec as in the forward kernel
     __shared__ float4 s_q0[BWD_BATCH];  // x, y, conic.x, conic.z
     __shared__ float4 s_q1[BWD_BATCH];  // conic.y, tau, opacity, Gaussian index (bits)
