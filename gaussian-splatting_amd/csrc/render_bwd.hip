@@ -43,10 +43,11 @@ template <int DIM, bool INVD>
 __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(8, 8)))
 render_bwd_kernel(const RenderBwdArgs a) {
     // same regrouping of the SplatRec as in the forward kernel
-    __shared__ float4 s_q0[BWD_BATCH];  // x, y, conic.x, conic.z
-    __shared__ float4 s_q1[BWD_BATCH];  // conic.y, tau, opacity, Gaussian index (bits)
-    __shared__ float4 s_q2[BWD_BATCH];  // r, g, b, 1/depth
-    __shared__ float4 s_q3[BWD_BATCH];  // rep0 .. rep3
+    __shared__ float4 s_q[4][BWD_BATCH];
+    float4* const s_q0 = s_q[0];  // x, y, conic.x, conic.z
+    float4* const s_q1 = s_q[1];  // conic.y, tau, opacity, Gaussian index (bits)
+    float4* const s_q2 = s_q[2];  // r, g, b, 1/depth
+    float4* const s_q3 = s_q[3];  // rep0 .. rep3
     __shared__ float s_acc[BWD_BATCH][16];
     __shared__ uint32_t s_max[4];
 
@@ -128,12 +129,21 @@ render_bwd_kernel(const RenderBwdArgs a) {
         }
         __syncthreads();
 
+        typedef __attribute__((address_space(3))) float4 lds_f4;
+        uint32_t qaddr = (uint32_t)(uintptr_t)(lds_f4*)&s_q[0][0];
+        asm volatile("" : "+v"(qaddr));
 #pragma unroll 1   // unrolling 2x / 4x changes nothing measurable
         for (int j = 0; j < nb; ++j) {
             const uint32_t contributor = (uint32_t)(max_last - 1 - base - j);
-            const float4 q0 = s_q0[j];
-            const float4 q1 = s_q1[j];
-            asm volatile("" : : "v"(q1.y), "v"(q1.z));  // one 16-byte LDS read
+            // the LDS address of entry j lives in a VGPR that is advanced per visit; all four reads of a
+            // visit use it with immediate offsets (the compiler would copy it from an SGPR before each)
+            float4 q0, q1;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(q0), "=&v"(q1)
+                         : "v"(qaddr), "i"((int)(BWD_BATCH * sizeof(float4)))
+                         : "memory");
+            const uint32_t qa = qaddr;
+            qaddr += 16;
             f2 d;
             const float power = splat_power_pk((f2){q0.x, q0.y}, pix, (f2){q0.z, q0.w}, q1.x, &d);
             const float dx = d.x, dy = d.y;
@@ -147,9 +157,17 @@ render_bwd_kernel(const RenderBwdArgs a) {
             const uint64_t vm = lanes_where(!(alpha < GS_ALPHA_MIN)) & pm;
             if (vm == 0) continue;
 
-            const float4 q2 = s_q2[j];
-            float4 q3 = make_float4(0, 0, 0, 0);
-            if (DIM == 4) q3 = s_q3[j];
+            float4 q2, q3 = make_float4(0, 0, 0, 0);
+            if (DIM == 4)
+                asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(q2), "=&v"(q3)
+                             : "v"(qa), "i"(2 * (int)(BWD_BATCH * sizeof(float4))), "i"(3 * (int)(BWD_BATCH * sizeof(float4)))
+                             : "memory");
+            else
+                asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(q2)
+                             : "v"(qa), "i"(2 * (int)(BWD_BATCH * sizeof(float4)))
+                             : "memory");
 
             // No branch around the arithmetic: a pixel outside vm takes part as a contributor with
             // alpha = 0 and G = 0.  Its transmittance stays as it is (T / (1 - 0), exactly), all 14

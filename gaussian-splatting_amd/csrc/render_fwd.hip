@@ -41,10 +41,11 @@ template <int DIM, bool INVD>
 __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6, 6))) render_fwd_kernel(const RenderFwdArgs a) {
     // One SplatRec per instance, regrouped: the test of an instance needs the first two
     // quarters only, the other two feed packed (two-float) multiply-adds as they are.
-    __shared__ float4 s_q0[TILE_PIX];  // x, y, conic.x, conic.z
-    __shared__ float4 s_q1[TILE_PIX];  // conic.y, tau, opacity, Gaussian index (bits)
-    __shared__ float4 s_q2[TILE_PIX];  // r, g, b, 1/depth
-    __shared__ float4 s_q3[TILE_PIX];  // rep0 .. rep3
+    __shared__ float4 s_q[4][TILE_PIX];
+    float4* const s_q0 = s_q[0];  // x, y, conic.x, conic.z
+    float4* const s_q1 = s_q[1];  // conic.y, tau, opacity, Gaussian index (bits)
+    float4* const s_q2 = s_q[2];  // r, g, b, 1/depth
+    float4* const s_q3 = s_q[3];  // rep0 .. rep3
     __shared__ float s_gsum[4][TILE_PIX];
     __shared__ uint32_t s_gcnt[4][TILE_PIX];
     __shared__ int s_wdone[4];
@@ -108,6 +109,12 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
                 }
                 continue;
             }
+            // LDS address of the group's first entry, pinned in a VGPR: the broadcast reads of the 16
+            // visits use it with immediate offsets (left to itself the compiler keeps the address in an
+            // SGPR and copies it into a VGPR, twice, in front of every visit's reads)
+            typedef __attribute__((address_space(3))) float4 lds_f4;
+            uint32_t gbase = (uint32_t)(uintptr_t)(lds_f4*)&s_q[0][j0];
+            asm volatile("" : "+v"(gbase));
             float tv[16];
             uint64_t cnt_lo = 0, cnt_hi = 0;  // byte u: number of pixels of the wave that tested instance j0 + u
 #pragma unroll
@@ -115,9 +122,11 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int j = j0 + u;
-                const float4 q0 = s_q0[j];
-                const float4 q1 = s_q1[j];
-                asm volatile("" : : "v"(q1.y), "v"(q1.z), "v"(q1.w));  // one 16-byte LDS read, not three sunk ones
+                float4 q0, q1;
+                asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(q0), "=&v"(q1)
+                             : "v"(gbase), "i"(16 * u), "i"((int)(TILE_PIX * sizeof(float4)) + 16 * u)
+                             : "memory");
                 f2 d;
                 const float power = splat_power_pk((f2){q0.x, q0.y}, pix, (f2){q0.z, q0.w}, q1.x, &d);
                 // forward.cu:423-432: the statistics count every pixel that reaches this instance with a
@@ -138,7 +147,18 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
                 live &= ~tm;
                 const uint64_t bm = am & ~tm;
                 if (bm == 0) continue;
-                const float4 q2 = s_q2[j];
+                float4 q2, q3 = make_float4(0, 0, 0, 0);
+                if (DIM == 4)
+                    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(q2), "=&v"(q3)
+                                 : "v"(gbase), "i"(2 * (int)(TILE_PIX * sizeof(float4)) + 16 * u),
+                                   "i"(3 * (int)(TILE_PIX * sizeof(float4)) + 16 * u)
+                                 : "memory");
+                else
+                    asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(q2)
+                                 : "v"(gbase), "i"(2 * (int)(TILE_PIX * sizeof(float4)) + 16 * u)
+                                 : "memory");
                 if (lane_in(bm)) {
                     // forward.cu:454-464: C += c * alpha * T per channel.  The weight alpha * T is formed
                     // once and each pair of channels is one packed fused multiply-add (the sums are
@@ -149,7 +169,6 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
                     Crg = __builtin_elementwise_fma((f2){q2.x, q2.y}, w2, Crg);
                     Cbd = __builtin_elementwise_fma((f2){q2.z, q2.w}, w2, Cbd);
                     if (DIM == 4) {
-                        const float4 q3 = s_q3[j];
                         R01 = __builtin_elementwise_fma((f2){q3.x, q3.y}, w2, R01);
                         R23 = __builtin_elementwise_fma((f2){q3.z, q3.w}, w2, R23);
                     }
