@@ -269,8 +269,8 @@ def roofline_entry(dom, ent, achieved_hbm, ab, traffic, ms):
         return {"kernel": dom, "bound": "valu", "achieved": v["achieved_Ginst_s"], "peak": v["peak_Ginst_s"],
                 "unit": "G wave64-instructions/s", "frac": v["frac"], "traffic": traffic,
                 "algorithmic_bytes_per_launch": ab, "ms_per_launch": ms, "limited_by": BOUND.get(dom),
-                "hbm_floor": hbm, "source": "SQ_INSTS_VALU per launch from profiles/pmc_traffic.json (rocprofv3 --pmc "
-                                            "passes of this command), duration live from HIP events"}
+                "hbm_floor": hbm, "source": "SQ_INSTS_VALU per launch from the committed rocprofv3 --pmc passes of this "
+                                            "command on this scene (profiles/pmc_traffic*.json), duration live from HIP events"}
     return dict({"kernel": dom, "bound": "hbm", "traffic": traffic, "algorithmic_bytes_per_launch": ab,
                  "ms_per_launch": ms, "limited_by": BOUND.get(dom)}, **hbm)
 
