@@ -157,6 +157,15 @@ __device__ __forceinline__ float splat_power_pk(f2 xy, f2 pix, f2 cxz, float cy,
     return -0.5f * (t.x + t.y) - cy * d->x * d->y;
 }
 
+// The same with the two squared terms' coefficients given as -0.5 * conic.x and -0.5 * conic.z: scaling
+// by a power of two commutes with every rounding, so the result has the same bits as splat_power_pk
+// and the multiplication by -0.5 per (pixel, instance) pair is paid once per instance instead.
+__device__ __forceinline__ float splat_power_prescaled(f2 xy, f2 pix, f2 mh_cxz, float cy, f2* d) {
+    *d = xy - pix;
+    const f2 t = mh_cxz * *d * *d;
+    return (t.x + t.y) - cy * d->x * d->y;
+}
+
 // gs_expf for the blend kernels: no clamps (callers only use the result on lanes whose
 // argument is in [-87, 0]) and the scaling by 2^n as one v_ldexp.  Same roundings as gs_expf
 // on that interval.

@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(8
 render_bwd_kernel(const RenderBwdArgs a) {
     // same regrouping of the SplatRec as in the forward kernel
     __shared__ float4 s_q[4][BWD_BATCH];
-    float4* const s_q0 = s_q[0];  // x, y, conic.x, conic.z
+    float4* const s_q0 = s_q[0];  // x, y, -conic.x / 2, -conic.z / 2 (see splat_power_prescaled)
     float4* const s_q1 = s_q[1];  // conic.y, tau, opacity, Gaussian index (bits)
     float4* const s_q2 = s_q[2];  // r, g, b, 1/depth
     float4* const s_q3 = s_q[3];  // rep0 .. rep3
@@ -113,7 +113,7 @@ render_bwd_kernel(const RenderBwdArgs a) {
             const uint32_t id = a.point_list[range.x + (uint32_t)(max_last - 1 - base - tid)];
             const float4* r4 = reinterpret_cast<const float4*>(a.rec + id);
             const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
-            s_q0[tid] = make_float4(r0.x, r0.y, r0.z, r1.x);
+            s_q0[tid] = make_float4(r0.x, r0.y, -0.5f * r0.z, -0.5f * r1.x);
             // tau as in the forward kernel: power below it cannot reach alpha >= 1/255; never below -87
             const float tau = fmaxf(-__logf(255.0f * r1.y) - 0.01f, -87.0f);
             s_q1[tid] = make_float4(r0.w, tau, r1.y, __uint_as_float(id));
@@ -145,9 +145,9 @@ render_bwd_kernel(const RenderBwdArgs a) {
             const uint32_t qa = qaddr;
             qaddr += 16;
             f2 d;
-            const float power = splat_power_pk((f2){q0.x, q0.y}, pix, (f2){q0.z, q0.w}, q1.x, &d);
+            const float power = splat_power_prescaled((f2){q0.x, q0.y}, pix, (f2){q0.z, q0.w}, q1.x, &d);
             const float dx = d.x, dy = d.y;
-            const V4 co = {q0.z, q1.x, q0.w, q1.z};  // conic.x, .y, .z, opacity
+            const V4 co = {q0.z, q1.x, q0.w, q1.z};  // -conic.x / 2, conic.y, -conic.z / 2, opacity (.y and .w are used)
             // backward.cu:592-611 as lane masks; pixels outside the image have last_contributor 0
             const uint64_t hm = lanes_where(contributor < last_contributor) & lanes_where(!(power > 0.0f));
             const uint64_t pm = lanes_where(power >= q1.y) & hm;
@@ -258,7 +258,7 @@ render_bwd_kernel(const RenderBwdArgs a) {
             if (comp_id < 2) {   // sums of h and k -> dL/dmean2D
                 const float other = s_acc[j][comp_id ^ 1];
                 const float4 q0 = s_q0[j];
-                v = (comp_id == 0 ? q0.z : q0.w) * v + s_q1[j].x * other;
+                v = -2.0f * (comp_id == 0 ? q0.z : q0.w) * v + s_q1[j].x * other;   // q0 holds -conic / 2
             }
             v *= scale;
             if (v != 0.0f) atomicAdd(a.acc + (size_t)__float_as_uint(s_q1[j].w) * 16 + (tid & 15), v);

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
     // One SplatRec per instance, regrouped: the test of an instance needs the first two
     // quarters only, the other two feed packed (two-float) multiply-adds as they are.
     __shared__ float4 s_q[4][TILE_PIX];
-    float4* const s_q0 = s_q[0];  // x, y, conic.x, conic.z
+    float4* const s_q0 = s_q[0];  // x, y, -conic.x / 2, -conic.z / 2 (see splat_power_prescaled)
     float4* const s_q1 = s_q[1];  // conic.y, tau, opacity, Gaussian index (bits)
     float4* const s_q2 = s_q[2];  // r, g, b, 1/depth
     float4* const s_q3 = s_q[3];  // rep0 .. rep3
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
             const uint32_t id = a.point_list[range.x + base + tid];
             const float4* r4 = reinterpret_cast<const float4*>(a.rec + id);
             const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
-            s_q0[tid] = make_float4(r0.x, r0.y, r0.z, r1.x);
+            s_q0[tid] = make_float4(r0.x, r0.y, -0.5f * r0.z, -0.5f * r1.x);
             // tau: the power below which alpha = opacity * exp(power) < 1/255 for certain, i.e.
             // -log(255 * opacity) less a margin that covers the rounding of the fast logarithm and of
             // the exponential by orders of magnitude.  Never below -87, where gs_expf stops falling:
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
             }
         } else if (tid < ((nb + 15) & ~15)) {
             // the last group of 16 is filled up with entries whose power is positive everywhere
-            s_q0[tid] = make_float4(-1e4f, -1e4f, -1.f, -1.f);
+            s_q0[tid] = make_float4(-1e4f, -1e4f, 0.5f, 0.5f);
             s_q1[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
                              : "v"(gbase), "i"(16 * u), "i"((int)(TILE_PIX * sizeof(float4)) + 16 * u)
                              : "memory");
                 f2 d;
-                const float power = splat_power_pk((f2){q0.x, q0.y}, pix, (f2){q0.z, q0.w}, q1.x, &d);
+                const float power = splat_power_prescaled((f2){q0.x, q0.y}, pix, (f2){q0.z, q0.w}, q1.x, &d);
                 // forward.cu:423-432: the statistics count every pixel that reaches this instance with a
                 // non-positive power, whatever its alpha
                 const uint64_t hm = lanes_where(!(power > 0.0f)) & live;
