@@ -266,8 +266,12 @@ def roofline_entry(dom, ent, achieved_hbm, ab, traffic, ms):
     hbm = {"achieved": achieved_hbm, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved_hbm / HBM_PEAK_GBPS}
     if BOUND.get(dom, "hbm").startswith("valu") and "valu" in ent:
         v = ent["valu"]
+        # note: this fraction is the share of the issue slots the kernel's own instruction stream fills; an
+        # optimisation that removes instructions lowers it together with the time (compare ms_per_launch and
+        # wave_insts_per_launch between builds)
         return {"kernel": dom, "bound": "valu", "achieved": v["achieved_Ginst_s"], "peak": v["peak_Ginst_s"],
                 "unit": "G wave64-instructions/s", "frac": v["frac"], "traffic": traffic,
+                "wave_insts_per_launch": v["wave_insts_per_launch"],
                 "algorithmic_bytes_per_launch": ab, "ms_per_launch": ms, "limited_by": BOUND.get(dom),
                 "hbm_floor": hbm, "source": "SQ_INSTS_VALU per launch from the committed rocprofv3 --pmc passes of this "
                                             "command on this scene (profiles/pmc_traffic*.json), duration live from HIP events"}
