@@ -742,12 +742,16 @@ GS_HD SsimOut ssim_point(float mu1, float ex2, float mu2, float ey2, float exy, 
     const float D = (2.0f * sigma12 + C2);
     const float A = (mu1_sq + mu2_sq + C1);
     const float B = (sigma1_sq + sigma2_sq + C2);
+    // The reference divides seven times by products of A and B; here the two reciprocals are formed once
+    // (the results agree to a few ulp; the map is compared with the reference's at 1e-5 relative).
+    const float rA = 1.0f / A, rB = 1.0f / B;
+    const float rAB = rA * rB;
+    const float m = (C * D) * rAB;
     SsimOut o;
-    o.m = (C * D) / (A * B);
-    o.dm_dmu1 = ((mu2 * 2.0f * D) / (A * B) - (mu2 * 2.0f * C) / (A * B) - (mu1 * 2.0f * C * D) / (A * A * B) +
-                 (mu1 * 2.0f * C * D) / (A * B * B));
-    o.dm_dsigma1_sq = ((-C * D) / (A * B * B));
-    o.dm_dsigma12 = ((2 * C) / (A * B));
+    o.m = m;
+    o.dm_dmu1 = 2.0f * (mu2 * (D - C) * rAB + mu1 * m * (rB - rA));
+    o.dm_dsigma1_sq = -m * rB;
+    o.dm_dsigma12 = (2.0f * C) * rAB;
     return o;
 }
 
