@@ -693,6 +693,22 @@ def main():
             extras.setdefault("optimizer_step_ms", {})[name] = 1e3 / timed(lambda: fn(opt), 10)
             del opt
 
+        # the loss of one view (not among `kernels`: the library's events only bracket the rasterizer):
+        # fused photometric loss + L1 on the feature channels, forward and backward, and the same composed
+        # from PyTorch operations around fused_ssim as train.py does
+        def loss_ms(fused):
+            img = torch.rand((3, H, W), device=dev).requires_grad_(True)
+            rp = torch.rand((4, H, W), device=dev).requires_grad_(True)
+            fake = (img, None, None, None, None, rp)
+
+            def f():
+                img.grad = None
+                rp.grad = None
+                train_loss(fake, gt0, fused=fused).backward()
+            return 1e3 / timed(f, 50)
+
+        extras["loss_ms_per_view"] = {"fused": loss_ms(True), "composed_in_torch": loss_ms(False)}
+
         # the stand-alone 64-bit sort on as many pairs as a view has instances
         extras["sort_u64"] = sort_u64_standalone(int(R), (gx * gy).bit_length(), dev)
 
