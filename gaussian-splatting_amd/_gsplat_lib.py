@@ -141,6 +141,8 @@ def lib():
     L.gso_densify_stats.argtypes = [C.c_int] + [_vp] * 6
     L.gso_densify_select.restype = C.c_int
     L.gso_densify_select.argtypes = [C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_float, C.c_float, C.c_int, _vp, _vp]
+    L.gso_mark_nonzero.restype = C.c_int
+    L.gso_mark_nonzero.argtypes = [C.c_int64, C.c_int, C.POINTER(C.c_void_p), _vp, _vp]
     L.gso_prune_mask.restype = C.c_int
     L.gso_prune_mask.argtypes = [C.c_int64, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp]
     L.gso_split_children.restype = C.c_int
@@ -163,7 +165,7 @@ EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backw
             "gsr_sort_pairs_u64_u32", "gsr_sort_noalloc_max_pairs", "gsr_sort_pairs_u64_u32_noalloc", "gsr_layout", "gsr_sorted_keys_u64", "gsk_dist2_temp_bytes", "gsk_dist2", "gss_ssim_forward",
             "gss_ssim_backward", "gss_loss_partial_floats", "gss_l1_ssim_loss_forward", "gss_l1_ssim_loss_backward",
             "gss_l1_partial_floats", "gss_l1_loss_forward", "gss_l1_loss_backward",
-            "gso_adam_update", "gso_densify_stats", "gso_densify_select", "gso_prune_mask", "gso_split_children", "gso_compact_temp_bytes", "gso_compact_map",
+            "gso_adam_update", "gso_densify_stats", "gso_densify_select", "gso_mark_nonzero", "gso_prune_mask", "gso_split_children", "gso_compact_temp_bytes", "gso_compact_map",
             "gso_gather_rows", "gsr_status_string")
 
 

@@ -526,6 +526,16 @@ int gso_split_children(int64_t K, int n, const uint32_t* parents, const float* x
                                             parent_of_child, (hipStream_t)stream));
 }
 
+int gso_mark_nonzero(int64_t N, int n, const int* const* counts, uint8_t* mask, void* stream) {
+    if (N < 0 || n < 0) return GSR_ERR_ARG;
+    if (N == 0) return GSR_OK;
+    if (!mask || (n > 0 && !counts)) return GSR_ERR_ARG;
+    if (((uintptr_t)mask & 3u) != 0) return GSR_ERR_ARG;
+    for (int v = 0; v < n; ++v)
+        if (!counts[v] || ((uintptr_t)counts[v] & 15u) != 0) return GSR_ERR_ARG;
+    return hip_status(launch_mark_nonzero(N, n, counts, mask, (hipStream_t)stream));
+}
+
 size_t gso_compact_temp_bytes(int64_t N) { return compact_temp_bytes(N > 0 ? N : 1); }
 
 int gso_compact_map(int64_t N, const uint8_t* keep, uint32_t* src_of_dst, void* temp, size_t temp_bytes, int64_t* kept,

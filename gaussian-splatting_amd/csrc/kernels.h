@@ -152,6 +152,8 @@ hipError_t launch_prune_mask(int64_t N, const float* opacity, const float* max_r
 hipError_t launch_split_children(int64_t K, int n, const uint32_t* parents, const float* xyz, const float* scaling,
                                  const float* rotation, const float* normals, float* new_xyz, float* new_scaling,
                                  uint32_t* parent_of_child, hipStream_t st);
+// counts: host array of n device pointers to [N] ints (4-byte aligned rows start 16-byte aligned); mask [N] bytes, 4-byte aligned
+hipError_t launch_mark_nonzero(int64_t N, int n, const int* const* counts, uint8_t* mask, hipStream_t st);
 hipError_t launch_scan_u32(uint32_t* sums, int nb, uint64_t* total, hipStream_t st);
 size_t compact_temp_bytes(int64_t N);
 hipError_t launch_compact_map(int64_t N, const uint8_t* keep, uint32_t* src_of_dst, void* temp, hipStream_t st,

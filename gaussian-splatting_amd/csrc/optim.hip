@@ -182,6 +182,37 @@ __global__ void __launch_bounds__(256) prune_mask_kernel(int64_t N, const float*
     mask[i] = m ? 1 : 0;
 }
 
+// mask[i] |= (counts[0][i] != 0) | ... | (counts[n-1][i] != 0) (accumulate), or = (overwrite): the Gaussians
+// that a pixel of some view reached, from the views' gauss_count outputs (forward.cu:431-432).  Four
+// Gaussians per thread: 16-byte loads of the counts, one 4-byte access of the mask.
+constexpr int MARK_MAX_ARRAYS = 8;
+struct MarkArgs {
+    const int* counts[MARK_MAX_ARRAYS];
+    int n;
+    int accumulate;
+    int64_t N;
+    uint8_t* mask;
+};
+
+__global__ void __launch_bounds__(256) mark_nonzero_kernel(const MarkArgs a) {
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= a.N) return;
+    if (i0 + 4 <= a.N) {
+        uint32_t m = a.accumulate ? *reinterpret_cast<const uint32_t*>(a.mask + i0) : 0u;
+        for (int v = 0; v < a.n; ++v) {
+            const int4 c = *reinterpret_cast<const int4*>(a.counts[v] + i0);
+            m |= (c.x != 0 ? 1u : 0u) | (c.y != 0 ? 1u << 8 : 0u) | (c.z != 0 ? 1u << 16 : 0u) | (c.w != 0 ? 1u << 24 : 0u);
+        }
+        *reinterpret_cast<uint32_t*>(a.mask + i0) = m;
+    } else {
+        for (int64_t i = i0; i < a.N; ++i) {
+            uint8_t m = a.accumulate ? a.mask[i] : (uint8_t)0;
+            for (int v = 0; v < a.n; ++v) m |= a.counts[v][i] != 0 ? 1 : 0;
+            a.mask[i] = m;
+        }
+    }
+}
+
 // densify_and_split (scene/gaussian_model.py:367-377): every selected Gaussian is replaced by n
 // children.  Child j (of K * n, laid out as `.repeat(n, 1)` lays them out: child j belongs to parent
 // j mod K) sits at parent position + R(q / |q|) (z_j * exp(scaling)), z_j a standard normal sample
@@ -232,6 +263,21 @@ hipError_t launch_prune_mask(int64_t N, const float* opacity, const float* max_r
     if (N <= 0) return hipSuccess;
     hipLaunchKernelGGL(prune_mask_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, opacity, max_radii2D,
                        scaling, min_opacity, max_screen_size, max_world_size, also, mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_nonzero(int64_t N, int n, const int* const* counts, uint8_t* mask, hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    if (n <= 0) return hipMemsetAsync(mask, 0, (size_t)N, st);
+    for (int first = 0; first < n; first += MARK_MAX_ARRAYS) {
+        MarkArgs a;
+        a.n = n - first < MARK_MAX_ARRAYS ? n - first : MARK_MAX_ARRAYS;
+        for (int v = 0; v < a.n; ++v) a.counts[v] = counts[first + v];
+        a.accumulate = first > 0;
+        a.N = N;
+        a.mask = mask;
+        hipLaunchKernelGGL(mark_nonzero_kernel, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, a);
+    }
     return hipGetLastError();
 }
 

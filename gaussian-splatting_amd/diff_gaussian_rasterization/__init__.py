@@ -267,9 +267,22 @@ class ParamGradSink:
         from such a pixel (backward.cu:591-611 walks the same pairs), so the rows of all other
         Gaussians are exactly zero: a data-parallel caller exchanges only the union of these rows."""
         P = self.num_gaussians()
-        t = torch.zeros((P,), dtype=torch.uint8, device=self.flat.device)
-        for c in self.hit_counts:
-            t |= c.view(-1).ne(0)
+        dev = self.flat.device
+        counts = [c.view(-1) for c in self.hit_counts]
+        if dev.type == "cuda" and all(c.is_cuda and c.dtype == torch.int32 and c.is_contiguous() and c.numel() == P
+                                      and c.data_ptr() % 16 == 0 for c in counts):
+            # one kernel over the views' counts (gso_mark_nonzero)
+            import ctypes
+            from _gsplat_lib import check, lib
+            t = torch.empty(((P + 3) // 4 * 4,), dtype=torch.uint8, device=dev)[:P]
+            ptrs = (ctypes.c_void_p * max(1, len(counts)))(*[c.data_ptr() for c in counts])
+            with torch.cuda.device(dev):
+                check(lib().gso_mark_nonzero(P, len(counts), ptrs, t.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream), "gso_mark_nonzero")
+            return t
+        t = torch.zeros((P,), dtype=torch.uint8, device=dev)
+        for c in counts:
+            t |= c.ne(0)
         return t
 
 

@@ -373,6 +373,13 @@ int gso_split_children(int64_t K, int n, const uint32_t* parents, const float* x
                        const float* rotation, const float* normals, float* new_xyz, float* new_scaling,
                        uint32_t* parent_of_child, void* stream);
 
+/* mask[i] = 1 if counts[v][i] != 0 for one of the n arrays, else 0.  No counterpart in the reference: the row
+ * mask of the Gaussians that some pixel of some view reached (the views' gauss_count outputs,
+ * forward.cu:431-432), whose gradient rows are the only non-zero ones of a step; a data-parallel caller
+ * exchanges those rows only.  counts: HOST array of n device pointers, each to [N] ints and 16-byte
+ * aligned; mask: device [N] bytes, 4-byte aligned. */
+int gso_mark_nonzero(int64_t N, int n, const int* const* counts, uint8_t* mask, void* stream);
+
 /* Row compaction for pruning (scene/gaussian_model.py:402-441, which keeps the rows of a mask in
  * every parameter, Adam moment and statistics tensor by boolean indexing: one host-blocking
  * nonzero() and one gather per tensor).  gso_compact_map turns the mask (device [N] bytes, nonzero =

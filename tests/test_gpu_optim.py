@@ -320,3 +320,21 @@ def test_densify_and_prune_matches_the_reference_formulation(max_screen_size):
     assert torch.equal(new_radii, model["tmp_radii"])
     for k in ("xyz_gradient_accum", "denom", "max_radii2D"):
         assert torch.equal(new_stats[k], model[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,narrays", [(1, 1), (3, 2), (1023, 8), (4096, 11), (100001, 0)])
+def test_mark_nonzero_is_the_or_of_the_counts(P, narrays):
+    """gso_mark_nonzero: the row mask of the Gaussians some view reached, from the views' hit counts (more
+    arrays than one launch takes, lengths that are not a multiple of four, no array at all)."""
+    import ctypes
+    from _gsplat_lib import check, lib
+    g = torch.Generator(device="cuda").manual_seed(P)
+    cs = [(torch.rand(P, device="cuda", generator=g) < 0.05).int() * 7 for _ in range(narrays)]
+    want = torch.stack(cs).ne(0).any(0) if cs else torch.zeros(P, dtype=torch.bool, device="cuda")
+    t = torch.full(((P + 3) // 4 * 4,), 255, dtype=torch.uint8, device="cuda")[:P]
+    ptrs = (ctypes.c_void_p * max(1, narrays))(*[c.data_ptr() for c in cs])
+    check(lib().gso_mark_nonzero(P, narrays, ptrs, t.data_ptr(), torch.cuda.current_stream().cuda_stream),
+          "gso_mark_nonzero")
+    torch.cuda.synchronize()
+    assert torch.equal(t, want.to(torch.uint8))
