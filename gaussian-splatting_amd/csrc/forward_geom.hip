@@ -215,23 +215,19 @@ struct PreBatchArgs {
     FwdBatchView v[MAX_FWD_BATCH_VIEWS];
 };
 
-#ifndef PRE_FWD_BATCH_WAVES
-#define PRE_FWD_BATCH_WAVES 2
-#endif
-#ifndef PRE_FWD_BATCH_UNROLL
-#define PRE_FWD_BATCH_UNROLL 1
-#endif
-__global__ void __launch_bounds__(PRE_BLOCK, PRE_FWD_BATCH_WAVES) preprocess_fwd_batch_kernel(const PreBatchArgs b) {
-    __shared__ __align__(16) char s_sh[4 * REST_WAVE_F * 4];
+// The SH row of a Gaussian goes straight into registers; the colours of all the views are evaluated
+// first and wait in LDS (6 KiB per wave), then the views are projected one after the other: the row's 48
+// registers and the projection's are never live together (82 VGPRs, 24 KiB of LDS per workgroup: 5 waves
+// per SIMD).  A first version kept the wave's rows as an LDS image (11.25 KiB per wave) next to the
+// projection's registers: 129 VGPRs, 3 waves per SIMD, 1.92 ms instead of 1.53 for 8 views.
+__global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_batch_kernel(const PreBatchArgs b) {
+    __shared__ float s_col[4][MAX_FWD_BATCH_VIEWS][3][64];
     __shared__ uint32_t s_tiles[MAX_FWD_BATCH_VIEWS][4];
     __shared__ uint32_t s_vis[MAX_FWD_BATCH_VIEWS][4];
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wave_g0 = blockIdx.x * PRE_BLOCK + w * 64;
-    const int nrows = min(64, b.P - wave_g0);  // <= 0 for waves past the end
     const bool live = idx < b.P;
     const size_t i = (size_t)(live ? idx : 0);
-    float* lds = reinterpret_cast<float*>(s_sh) + w * REST_WAVE_F;
 
     const V3 p = v3(b.means3D[3 * i], b.means3D[3 * i + 1], b.means3D[3 * i + 2]);
     float cov6[6];
@@ -248,39 +244,39 @@ __global__ void __launch_bounds__(PRE_BLOCK, PRE_FWD_BATCH_WAVES) preprocess_fwd
         }
         cov3d_from_scale_rot(sc, b.mod, q, cov6);
     }
-
-    // The SH row is fetched for every Gaussian that lies in front of at least one camera (the near
-    // test of the preprocess; cheap).  Some of those turn out to be off screen in every view and
-    // their row was fetched for nothing, which costs less than finding out exactly: that would
-    // take the whole projection, once more per view.
-    bool maybe = false;
+    uint32_t front = 0;   // bit v: in front of camera v's near plane
     if (live) {
 #pragma unroll 1
         for (int v = 0; v < b.nviews; ++v) {
             float vm[16], depth;
 #pragma unroll
             for (int k = 0; k < 16; ++k) vm[k] = b.v[v].cam.view[k];
-            maybe = maybe || !near_cull(p, vm, &depth);
+            if (!near_cull(p, vm, &depth)) front |= 1u << v;
         }
     }
-    const uint64_t rows = __ballot(maybe);
-    if (rows && nrows > 0)
-        rest_rows_copy<0>(const_cast<float*>(b.shs_rest) + (size_t)wave_g0 * REST_ROW_F, lds, rows, nrows, lane);
-    wave_lds_sync();
-    // coefficient 0 from registers, the others from the lane's row in LDS (row stride 45 dwords: odd,
-    // no bank conflicts); keeping the row out of the registers leaves them to the projection
-    struct ShRow {
-        float dc0, dc1, dc2;
-        const float* row;
-        __device__ __forceinline__ V3 operator()(int k) const {
-            return k == 0 ? v3(dc0, dc1, dc2) : v3(row[3 * k - 3], row[3 * k - 2], row[3 * k - 1]);
+    if (front) {
+        float shv[SH_ROW_F];
+        shv[0] = b.shs[3 * i];
+        shv[1] = b.shs[3 * i + 1];
+        shv[2] = b.shs[3 * i + 2];
+        const float* rest = b.shs_rest + i * REST_ROW_F;
+#pragma unroll
+        for (int k = 0; k < REST_ROW_F; ++k) shv[3 + k] = rest[k];
+        const ShRegs sh = {shv};
+#pragma unroll 1
+        for (int v = 0; v < b.nviews; ++v) {
+            if (!((front >> v) & 1u)) continue;
+            const float* cp = b.v[v].cam.campos;
+            const V3 col = sh_to_rgb(b.D, p, v3(cp[0], cp[1], cp[2]), sh);
+            s_col[w][v][0][lane] = col.x;
+            s_col[w][v][1][lane] = col.y;
+            s_col[w][v][2][lane] = col.z;
         }
-    };
-    const ShRow sh = {b.shs[3 * i], b.shs[3 * i + 1], b.shs[3 * i + 2], lds + lane * REST_ROW_F};
+    }
     float4 rp = make_float4(0, 0, 0, 0);
     if (b.DIM == 4) rp = reinterpret_cast<const float4*>(b.reps)[i];
 
-#pragma unroll PRE_FWD_BATCH_UNROLL
+#pragma unroll 1
     for (int v = 0; v < b.nviews; ++v) {
         const FwdBatchView& bv = b.v[v];
         uint32_t tiles = 0;
@@ -292,7 +288,7 @@ __global__ void __launch_bounds__(PRE_BLOCK, PRE_FWD_BATCH_WAVES) preprocess_fwd
             if (!near_cull(p, c.view, &depth)) {
                 Splat sp;
                 if (project_splat(c, p, cov6, opac, depth, &sp)) {
-                    V3 col = sh_to_rgb(b.D, p, v3(c.campos[0], c.campos[1], c.campos[2]), sh);
+                    V3 col = v3(s_col[w][v][0][lane], s_col[w][v][1][lane], s_col[w][v][2][lane]);
                     bv.clamped[i] = (uint8_t)((col.x < 0 ? 1 : 0) | (col.y < 0 ? 2 : 0) | (col.z < 0 ? 4 : 0));
                     col = v3(fmax_(col.x, 0.0f), fmax_(col.y, 0.0f), fmax_(col.z, 0.0f));
                     float4* r4 = reinterpret_cast<float4*>(bv.rec + i);
