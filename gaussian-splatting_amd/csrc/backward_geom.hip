@@ -358,16 +358,38 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
     uint32_t seen = 0;  // bit v: rendered in view v and reached by a pixel there (else its GradRec is zero)
     for (int v = 0; v < b.nviews; ++v) {
         if (!live) break;
-        if (b.v[v].radii[i] > 0 && b.v[v].gstat[i].count != 0u) {
-            seen |= 1u << v;
-        } else if (b.v[v].dL_dmeans2D) {  // the screen-space gradient of a view is per view: zero here
-            float* m2 = b.v[v].dL_dmeans2D + 3 * i;
-            m2[0] = m2[1] = m2[2] = 0.f;
-        }
+        // a hit count can only be non-zero for a Gaussian that was rendered (radius > 0): one array to read
+        if (b.v[v].gstat[i].count != 0u) seen |= 1u << v;
     }
     const uint64_t rows = __ballot(seen != 0);
-    if (rows == 0 && a.accumulate) return;
-    if (rows) rest_rows_copy<0>(const_cast<float*>(a.shs_rest) + (size_t)wave_g0 * REST_ROW_F, lds, rows, nrows, lane);
+    if (rows == 0) {
+        // No Gaussian of this wave was reached in any view (in a heavily occluded scene: nearly every
+        // wave).  The screen-space gradients of the views are zero here, and so are, when overwriting,
+        // the wave's rows of every parameter gradient: each tensor's block of 64 rows is contiguous and
+        // is zeroed with whole-wave 16-byte stores in address order (a lane storing its own row's three
+        // floats makes every store instruction touch 64 lines a third full).
+        const size_t g0 = (size_t)wave_g0;
+        for (int v = 0; v < b.nviews; ++v)
+            if (b.v[v].dL_dmeans2D) wave_zero_bytes(b.v[v].dL_dmeans2D + 3 * g0, nrows * 12, lane);
+        if (a.accumulate) return;
+        wave_zero_bytes(a.dL_dsh + 3 * g0, nrows * 12, lane);
+        wave_zero_bytes(a.dL_dopacity + g0, nrows * 4, lane);
+        wave_zero_bytes(a.dL_dmeans3D + 3 * g0, nrows * 12, lane);
+        wave_zero_bytes(a.dL_dscales + 3 * g0, nrows * 12, lane);
+        wave_zero_bytes(a.dL_drotations + 4 * g0, nrows * 16, lane);
+        if (a.DIM == 4) wave_zero_bytes(a.dL_dreps + 4 * g0, nrows * 16, lane);
+        wave_zero_bytes(a.dL_dsh_rest + g0 * REST_ROW_F, nrows * REST_ROW_F * 4, lane);
+        return;
+    }
+    if (live) {   // the screen-space gradient of a view is per view: zero where the view did not reach the Gaussian
+        for (int v = 0; v < b.nviews; ++v) {
+            if (!((seen >> v) & 1u) && b.v[v].dL_dmeans2D) {
+                float* m2 = b.v[v].dL_dmeans2D + 3 * i;
+                m2[0] = m2[1] = m2[2] = 0.f;
+            }
+        }
+    }
+    rest_rows_copy<0>(const_cast<float*>(a.shs_rest) + (size_t)wave_g0 * REST_ROW_F, lds, rows, nrows, lane);
     wave_lds_sync();
 
     V3 dmean = v3(0, 0, 0);

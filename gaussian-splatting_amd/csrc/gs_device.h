@@ -302,6 +302,16 @@ __device__ __forceinline__ void rest_rows_copy(float* __restrict__ g, float* lds
     }
 }
 
+// Zeroes `bytes` bytes (a multiple of 4) at `p` (16-byte aligned) with the whole wave: 16 bytes per lane
+// and step in address order, dwords for what is left.
+__device__ __forceinline__ void wave_zero_bytes(void* p, int bytes, int lane) {
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const int n4 = bytes >> 4;
+    for (int i = lane; i < n4; i += 64) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int f = (n4 << 2) + lane;
+    if (f < (bytes >> 2)) reinterpret_cast<float*>(p)[f] = 0.f;
+}
+
 // How a per-Gaussian kernel gets at the SH rows: none (precomputed colours), each lane walking its own
 // row in global memory (any row size), or the wave's 64 rows staged through LDS in 16-byte chunks
 // (16 coefficients; one [P,16,3] tensor, or [P,1,3] + [P,15,3]).

@@ -201,7 +201,9 @@ typedef struct {
     int W, H;
     int antialiasing;
     int has_invdepth;          /* that view's backward was given dL_dout_invdepth */
-    const int* radii;          /* device [P], from that view's forward */
+    const int* radii;          /* device [P], from that view's forward (kept for symmetry with gsr_backward; the
+                                  batch call does not read it: the hit counts in the geometry buffer say which
+                                  Gaussians a view reached, and only rendered ones can have been reached) */
     const void* geom_buffer;   /* that view's geometry buffer */
     const void* work;          /* that view's accumulators, filled by gsr_backward_blend */
     float* dL_dmeans2D;        /* device [P,3] or NULL: that view's screen-space gradient, written by the batch call
