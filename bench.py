@@ -373,6 +373,9 @@ def main():
     ap.add_argument("--torch-loss", action="store_true",
                     help="compose the photometric loss from PyTorch operations around fused_ssim, as train.py does, "
                          "instead of fused_ssim.l1_ssim_loss (the reference-signature runs always do)")
+    ap.add_argument("--rewrite-zero-rows", action="store_true",
+                    help="ParamGradSink without keep_zero_rows: every gradient row is written in every step, also "
+                         "the all-zero rows of Gaussians no view reached that were zero before")
     ap.add_argument("--no-defer", action="store_true",
                     help="run the per-Gaussian backward after every view instead of once per step for all its views")
     ap.add_argument("--reduce-chunks", type=int, default=6,
@@ -429,7 +432,8 @@ def main():
     leaves = list(params.values())
     use_params = args.api == "params"
     fused_loss = use_params and not args.torch_loss
-    sink = ParamGradSink(*leaves, defer=not args.no_defer) if use_params else None
+    sink = ParamGradSink(*leaves, defer=not args.no_defer, keep_zero_rows=not args.rewrite_zero_rows) \
+        if use_params else None
     log(f"[rank {rank}] scene ready in {time.time() - t0:.1f}s")
 
     def one_view(rs, gt):
@@ -809,6 +813,8 @@ def main():
                                    (", forward only" if args.fwd_only else ", each fwd + fused-ssim loss + bwd, then the "
                                     "sum of the gradients over the GPUs when n_gpus > 1 (see allreduce); no optimizer"),
                        "api": "forward_params (raw parameters)" if use_params else "reference signature",
+                       "gradient_buffers": ("persistent; blocks of rows that are zero and stay zero are not rewritten"
+                                            if use_params and sink.row_blocks is not None else "every row written"),
                        "streams": 1 + len(side_streams),
                        "loss": ("fused_ssim.l1_ssim_loss + fused_ssim.l1_loss on the reps" if fused_loss else
                                 "PyTorch L1 / clamp around fused_ssim + reps L1 (as train.py)"),

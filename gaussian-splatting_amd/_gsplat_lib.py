@@ -36,13 +36,13 @@ class GsrBackwardIO(C.Structure):
     _fields_ = [(n, _vp) for n in ("dL_dout_color", "dL_dout_invdepth", "dL_dout_reps", "dL_dmeans2D", "dL_dcolors",
                                    "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations",
                                    "dL_dreps", "work")] + \
-               [("work_bytes", C.c_size_t), ("dL_dsh_rest", _vp), ("accumulate", C.c_int)]
+               [("work_bytes", C.c_size_t), ("dL_dsh_rest", _vp), ("accumulate", C.c_int), ("row_blocks", _vp)]
 
 
 class GsrBackwardView(C.Structure):
     _fields_ = [("viewmatrix", _vp), ("projmatrix", _vp), ("campos", _vp), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
                 ("W", C.c_int), ("H", C.c_int), ("antialiasing", C.c_int), ("has_invdepth", C.c_int), ("radii", _vp),
-                ("geom_buffer", _vp), ("work", _vp), ("dL_dmeans2D", _vp)]
+                ("geom_buffer", _vp), ("work", _vp), ("dL_dmeans2D", _vp), ("means2D_blocks", _vp)]
 
 
 class GsrForwardView(C.Structure):

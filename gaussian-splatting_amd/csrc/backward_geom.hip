@@ -52,6 +52,7 @@ struct PreBwdArgs {
     float* dL_dscales;
     float* dL_drotations;
     float* dL_dreps;
+    uint8_t* row_blocks;  // batch kernel only, may be null: see GsrBackwardIO.row_blocks
 };
 
 
@@ -329,6 +330,7 @@ struct BatchView {
     const uint8_t* clamped;
     const GradRec* acc;
     float* dL_dmeans2D;  // [P,3] of this view, or null
+    uint8_t* m2_blocks;  // may be null: see GsrBackwardView.means2D_blocks
 };
 
 struct PreBwdBatchArgs {
@@ -355,23 +357,63 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
     float* lds = reinterpret_cast<float*>(s_sh + w * WAVE_LDS);
     float* row = lds + lane * REST_ROW_F;
 
-    uint32_t seen = 0;  // bit v: rendered in view v and reached by a pixel there (else its GradRec is zero)
-    for (int v = 0; v < b.nviews; ++v) {
-        if (!live) break;
+    // All the loads that decide what this wave does are issued before the first of them is waited for
+    // (eight views' hit counts, up to nine block states: one memory latency, not seventeen in a row; the
+    // launcher points the unused views at view 0's counts so that no load depends on the view count).
+    const size_t g0 = (size_t)wave_g0;
+    const int blk = wave_g0 >> 6;
+    uint32_t cnt[MAX_BATCH_VIEWS];
+    uint32_t m2_state[MAX_BATCH_VIEWS];
+    const uint8_t* valid = reinterpret_cast<const uint8_t*>(b.v[0].gstat);
+#pragma unroll
+    for (int v = 0; v < MAX_BATCH_VIEWS; ++v) {
         // a hit count can only be non-zero for a Gaussian that was rendered (radius > 0): one array to read
-        if (b.v[v].gstat[i].count != 0u) seen |= 1u << v;
+        cnt[v] = b.v[v].gstat[i].count;
+        m2_state[v] = *(b.v[v].m2_blocks ? b.v[v].m2_blocks + blk : valid);   // an absent state array: any valid byte
     }
+    uint32_t row_state = *(a.row_blocks ? a.row_blocks + blk : valid);
+    // (the values pass through an empty asm statement here: left alone, the compiler sinks the state loads
+    // below the first use of the counts, and the wave waits for memory twice)
+    static_assert(MAX_BATCH_VIEWS == 8, "the statement below names eight states");
+    asm volatile("" : "+v"(m2_state[0]), "+v"(m2_state[1]), "+v"(m2_state[2]), "+v"(m2_state[3]), "+v"(m2_state[4]),
+                      "+v"(m2_state[5]), "+v"(m2_state[6]), "+v"(m2_state[7]), "+v"(row_state));
+#pragma unroll
+    for (int v = 0; v < MAX_BATCH_VIEWS; ++v)
+        if (!b.v[v].m2_blocks) m2_state[v] = 1;
+    if (!a.row_blocks) row_state = 1;
+    uint32_t seen = 0;  // bit v: rendered in view v and reached by a pixel there (else its GradRec is zero)
+#pragma unroll
+    for (int v = 0; v < MAX_BATCH_VIEWS; ++v)
+        if (live && v < b.nviews && cnt[v] != 0u) seen |= 1u << v;
     const uint64_t rows = __ballot(seen != 0);
+    // Block states (one byte per 64 Gaussians = per wave, optional): a zero byte says that the block's
+    // rows of a gradient tensor are all zero already; such a block is not rewritten with zeros, and the
+    // byte is kept up to date (lane 0 stores it; nobody else reads or writes this block's byte).
+#pragma unroll
+    for (int v = 0; v < MAX_BATCH_VIEWS; ++v) {   // the screen-space gradient of a view: zero where it did not reach
+        if (v >= b.nviews) break;
+        const BatchView& bv = b.v[v];
+        if (!bv.dL_dmeans2D) continue;
+        if (__ballot((seen >> v) & 1u) == 0) {
+            // whole-wave 16-byte stores in address order (a lane storing its own three floats would make
+            // every store instruction touch 64 lines a third full)
+            if (m2_state[v] == 0) continue;
+            wave_zero_bytes(bv.dL_dmeans2D + 3 * g0, nrows * 12, lane);
+            if (bv.m2_blocks && lane == 0) bv.m2_blocks[blk] = 0;
+        } else {
+            if (live && !((seen >> v) & 1u)) {
+                float* m2 = bv.dL_dmeans2D + 3 * i;
+                m2[0] = m2[1] = m2[2] = 0.f;
+            }
+            if (bv.m2_blocks && lane == 0) bv.m2_blocks[blk] = 1;
+        }
+    }
     if (rows == 0) {
         // No Gaussian of this wave was reached in any view (in a heavily occluded scene: nearly every
-        // wave).  The screen-space gradients of the views are zero here, and so are, when overwriting,
-        // the wave's rows of every parameter gradient: each tensor's block of 64 rows is contiguous and
-        // is zeroed with whole-wave 16-byte stores in address order (a lane storing its own row's three
-        // floats makes every store instruction touch 64 lines a third full).
-        const size_t g0 = (size_t)wave_g0;
-        for (int v = 0; v < b.nviews; ++v)
-            if (b.v[v].dL_dmeans2D) wave_zero_bytes(b.v[v].dL_dmeans2D + 3 * g0, nrows * 12, lane);
+        // wave): when overwriting, the wave's rows of every parameter gradient are zero.  Each tensor's
+        // block of 64 rows is contiguous and is zeroed like the screen-space gradients above.
         if (a.accumulate) return;
+        if (row_state == 0) return;
         wave_zero_bytes(a.dL_dsh + 3 * g0, nrows * 12, lane);
         wave_zero_bytes(a.dL_dopacity + g0, nrows * 4, lane);
         wave_zero_bytes(a.dL_dmeans3D + 3 * g0, nrows * 12, lane);
@@ -379,16 +421,10 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
         wave_zero_bytes(a.dL_drotations + 4 * g0, nrows * 16, lane);
         if (a.DIM == 4) wave_zero_bytes(a.dL_dreps + 4 * g0, nrows * 16, lane);
         wave_zero_bytes(a.dL_dsh_rest + g0 * REST_ROW_F, nrows * REST_ROW_F * 4, lane);
+        if (a.row_blocks && lane == 0) a.row_blocks[blk] = 0;
         return;
     }
-    if (live) {   // the screen-space gradient of a view is per view: zero where the view did not reach the Gaussian
-        for (int v = 0; v < b.nviews; ++v) {
-            if (!((seen >> v) & 1u) && b.v[v].dL_dmeans2D) {
-                float* m2 = b.v[v].dL_dmeans2D + 3 * i;
-                m2[0] = m2[1] = m2[2] = 0.f;
-            }
-        }
-    }
+    if (a.row_blocks && lane == 0) a.row_blocks[blk] = 1;
     rest_rows_copy<0>(const_cast<float*>(a.shs_rest) + (size_t)wave_g0 * REST_ROW_F, lds, rows, nrows, lane);
     wave_lds_sync();
 
@@ -585,6 +621,7 @@ hipError_t launch_preprocess_bwd_batch(const GsrScene& s, int nviews, const GsrB
     a.dL_dopacity = io.dL_dopacity; a.dL_dmeans3D = io.dL_dmeans3D; a.dL_dsh = io.dL_dsh;
     a.dL_dsh_rest = io.dL_dsh_rest; a.dL_dscales = io.dL_dscales; a.dL_drotations = io.dL_drotations;
     a.dL_dreps = io.dL_dreps;
+    a.row_blocks = io.row_blocks;
     const dim3 grid((count + 255) / 256), block(256);
     for (int v0 = 0; v0 < nviews; v0 += MAX_BATCH_VIEWS) {
         b.nviews = nviews - v0 < MAX_BATCH_VIEWS ? nviews - v0 : MAX_BATCH_VIEWS;
@@ -601,6 +638,11 @@ hipError_t launch_preprocess_bwd_batch(const GsrScene& s, int nviews, const GsrB
             bv.gstat = gb.gstat;
             bv.acc = (const GradRec*)gv.work;
             bv.dL_dmeans2D = gv.dL_dmeans2D;
+            bv.m2_blocks = gv.dL_dmeans2D ? gv.means2D_blocks : nullptr;
+        }
+        for (int k = b.nviews; k < MAX_BATCH_VIEWS; ++k) {   // every view's count pointer is dereferenced
+            b.v[k] = BatchView();
+            b.v[k].gstat = b.v[0].gstat;
         }
         hipLaunchKernelGGL(preprocess_bwd_batch_kernel, grid, block, 0, st, b);
     }

@@ -243,11 +243,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
 def rasterize_gaussians_backward_blend(background, means3D, radii, opacities, scales, rotations, scale_modifier,
                                        viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_invdepth,
                                        dL_dout_reps, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
-                                       antialiasing, debug, reps, sh_rest, raw_params, want_means2D=True):
+                                       antialiasing, debug, reps, sh_rest, raw_params, want_means2D=True,
+                                       means2D_out=None):
     """First half of the backward for one view (no counterpart in the reference):
     the blend backward into a fresh per-Gaussian accumulator buffer.  Returns
     (dL_dmeans2D, work); `work` goes to backward_geometry_batch later, which
-    can also fill dL_dmeans2D (want_means2D=False leaves it uninitialised here)."""
+    can also fill dL_dmeans2D (want_means2D=False leaves it uninitialised here;
+    `means2D_out`, a [P,3] float32 tensor, is then returned in its place)."""
     L = lib()
     sort_errors.poll()
     dev = means3D.device
@@ -259,7 +261,13 @@ def rasterize_gaussians_backward_blend(background, means3D, radii, opacities, sc
                    projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, False, antialiasing, debug, reps, keep,
                    sh_rest=sh_rest, raw=raw_params)
         f32 = dict(dtype=torch.float32, device=dev)
-        dL_dmeans2D = torch.empty((P, 3), **f32)
+        if means2D_out is not None and not want_means2D:
+            if means2D_out.shape != (P, 3) or means2D_out.dtype != torch.float32 or means2D_out.device != dev or \
+                    not means2D_out.is_contiguous():
+                raise RuntimeError(f"means2D_out must be a contiguous float32 [P, 3] tensor on {dev}")
+            dL_dmeans2D = means2D_out
+        else:
+            dL_dmeans2D = torch.empty((P, 3), **f32)
         work = torch.empty((L.gsr_backward_work_bytes(P),), dtype=torch.uint8, device=dev)
         if P != 0:
             gc = dev_f32(dL_dout_color, dev, "dL_dout_color")
@@ -276,8 +284,16 @@ def rasterize_gaussians_backward_blend(background, means3D, radii, opacities, sc
     return dL_dmeans2D, work
 
 
+def _blocks(t, P, dev):
+    """A block-state array for P Gaussians (or None), checked."""
+    if t is not None and (t.dtype != torch.uint8 or t.device != dev or not t.is_contiguous()
+                          or t.numel() != (P + 63) // 64):
+        raise RuntimeError(f"a block-state array must be a contiguous uint8 tensor of (P + 63) // 64 bytes on {dev}")
+    return t
+
+
 def backward_geometry_batch(means3D, opacities, scales, rotations, scale_modifier, sh, sh_rest, degree, reps, raw_params,
-                            views, into, accumulate, debug=False, first=0, count=None):
+                            views, into, accumulate, debug=False, first=0, count=None, row_blocks=None):
     """Second half of the backward for a batch of views: `views` is a list of
     dicts (viewmatrix, projmatrix, campos, tanfovx, tanfovy, W, H, antialiasing,
     has_invdepth, radii, geom, work and optionally dL_dmeans2D, a [P,3] tensor
@@ -285,7 +301,10 @@ def backward_geometry_batch(means3D, opacities, scales, rotations, scale_modifie
     views are written (or, with `accumulate`, added) into the tensors of `into`
     (keys means3D, opacity, sh, sh_rest, scales, rotations, reps).  `first`, `count`:
     only the Gaussians [first, first + count) (first a multiple of 256); rows
-    outside the range are not touched."""
+    outside the range are not touched.  `row_blocks` and a view's
+    `means2D_blocks` (uint8 [(P + 63) // 64]): per block of 64 Gaussians whether
+    the gradient tensors / that view's dL_dmeans2D hold anything but zeros there;
+    blocks that are zero and stay zero are not rewritten (GsrBackwardIO.row_blocks)."""
     L = lib()
     dev = means3D.device
     P = means3D.size(0)
@@ -309,6 +328,8 @@ def backward_geometry_batch(means3D, opacities, scales, rotations, scale_modifie
             arr[k].antialiasing, arr[k].has_invdepth = int(bool(v["antialiasing"])), int(bool(v["has_invdepth"]))
             arr[k].radii, arr[k].geom_buffer, arr[k].work = ptr(v["radii"]), ptr(v["geom"]), ptr(v["work"])
             arr[k].dL_dmeans2D = ptr(v.get("dL_dmeans2D"))
+            arr[k].means2D_blocks = ptr(_blocks(v.get("means2D_blocks"), P, dev)) \
+                if v.get("dL_dmeans2D") is not None else None
         io = GsrBackwardIO()
         for key, field in (("means3D", "dL_dmeans3D"), ("opacity", "dL_dopacity"), ("sh", "dL_dsh"),
                            ("sh_rest", "dL_dsh_rest"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"),
@@ -318,6 +339,7 @@ def backward_geometry_batch(means3D, opacities, scales, rotations, scale_modifie
                 raise RuntimeError(f"gradient buffer '{key}' must be a contiguous float32 tensor on {dev}")
             setattr(io, field, ptr(t))
         io.accumulate = int(bool(accumulate))
+        io.row_blocks = ptr(_blocks(row_blocks, P, dev))
         check(L.gsr_backward_geometry_batch_range(C.byref(s), len(views), arr, C.byref(io), int(first), int(count),
                                                   stream_of(dev)), "backward_geometry_batch")
 

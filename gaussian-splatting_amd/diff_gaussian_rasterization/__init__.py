@@ -124,13 +124,26 @@ class ParamGradSink:
     NAMES = ("means3D", "sh", "sh_rest", "opacity", "scales", "rotations", "reps")
     ROW_ALIGN = 256   # Gaussian ranges of a chunked flush start at multiples of this
 
-    def __init__(self, xyz, features_dc, features_rest, opacity, scaling, rotation, reps=None, defer=False):
+    def __init__(self, xyz, features_dc, features_rest, opacity, scaling, rotation, reps=None, defer=False,
+                 keep_zero_rows=False):
         """defer: a view's backward only runs the blend backward (and returns the
         screen-space gradient); the per-Gaussian backward of all the views of a
         step runs once, in `flush()`, reading every parameter and writing every
         gradient a single time.  Call `flush()` before using the gradients: the
         parameters' and also the `means2D.grad` of the deferred views, which
-        `flush()` fills."""
+        `flush()` fills.
+
+        keep_zero_rows (with defer): the gradient rows of a Gaussian that no view of the
+        step reached are zero (see `touched_rows`), and in an occluded scene that is
+        nearly all of them, step after step.  The sink then remembers per block of 64
+        Gaussians whether the buffers hold anything but zeros there, and `flush()`
+        does not write zeros over zeros (`GsrBackwardIO.row_blocks`).  The results
+        are the same complete gradients.  Two conditions come with it: (1) whoever
+        else writes into the gradient buffers (another loss term's backward adding to
+        `.grad`, a collective that adds other GPUs' rows) calls `mark_rows_dirty`
+        afterwards (`gsdp.reduce_flush` does); (2) the `means2D.grad` tensors of the
+        views come from a pool that the next step reuses, so they are valid until the
+        next step's `flush()` (train.py reads them right after `backward()`)."""
         self.params = dict(means3D=xyz, sh=features_dc, sh_rest=features_rest, opacity=opacity, scales=scaling,
                            rotations=rotation, reps=reps)
         live = [(k, p) for k, p in self.params.items() if p is not None and p.numel() != 0]
@@ -148,6 +161,34 @@ class ParamGradSink:
         self.pending = []
         self.prepared = []
         self.hit_counts = []
+        # block states, see keep_zero_rows: `flat` starts as zeros, so every block starts clean
+        self.row_blocks = None
+        self.m2_pool, self.m2_next = [], 0
+        if keep_zero_rows and self.defer and like.is_cuda:
+            self.row_blocks = torch.zeros(((like.size(0) + 63) // 64,), dtype=torch.uint8, device=like.device)
+
+    def mark_rows_dirty(self, rows=None):
+        """Tell the sink that something other than its own backward wrote non-zero values into the
+        gradient rows `rows` (int64 indices; None: any row).  Only matters with keep_zero_rows."""
+        if self.row_blocks is None:
+            return
+        if rows is None:
+            self.row_blocks.fill_(1)
+        elif rows.numel() != 0:
+            self.row_blocks.index_fill_(0, rows.to(self.row_blocks.device, torch.int64) >> 6, 1)
+
+    def take_means2D(self):
+        """(dL_dmeans2D [P,3], its block states) for the next deferred view of this step: from the
+        pool (slot k serves the k-th backward of every step), or None without keep_zero_rows."""
+        if self.row_blocks is None:
+            return None
+        if self.m2_next == len(self.m2_pool):
+            P, dev = self.num_gaussians(), self.flat.device
+            self.m2_pool.append((torch.zeros((P, 3), dtype=torch.float32, device=dev),
+                                 torch.zeros_like(self.row_blocks)))
+        slot = self.m2_pool[self.m2_next]
+        self.m2_next += 1
+        return slot
 
     def attach(self):
         """(Re-)install the buffers as the parameters' `.grad`: `optimizer.zero_grad(set_to_none=True)`
@@ -165,6 +206,7 @@ class ParamGradSink:
         self.pending = []
         self.prepared = []
         self.hit_counts = []
+        self.m2_next = 0
         self.fresh = True
         self.attach()
 
@@ -220,7 +262,7 @@ class ParamGradSink:
         empty = torch.Tensor([])
         _C.backward_geometry_batch(p["means3D"], p["opacity"], p["scales"], p["rotations"], scale_modifier, p["sh"],
                                    p["sh_rest"], degree, empty if p["reps"] is None else p["reps"], True, views,
-                                   self.grads, accumulate, debug, first=first, count=count)
+                                   self.grads, accumulate, debug, first=first, count=count, row_blocks=self.row_blocks)
 
     def flush(self, chunks=1, on_chunk=None):
         """Run the per-Gaussian backward of the views whose backward was deferred.
@@ -242,6 +284,8 @@ class ParamGradSink:
                 groups.append((v["cfg"], [v]))
         if not groups and on_chunk is not None and self.fresh:
             self.flat.zero_()
+            if self.row_blocks is not None:
+                self.row_blocks.zero_()
             self.fresh = False
         for first, count in self.chunk_bounds(chunks if (groups or on_chunk is not None) else 1):
             accumulate = not self.fresh
@@ -327,18 +371,20 @@ class _RasterizeGaussiansParams(torch.autograd.Function):
         if sink is not None:
             sink.hit_counts.append(ctx.gauss_count)
         if sink is not None and sink.defer:
+            slot = sink.take_means2D()
             g_means2D, work = _C.rasterize_gaussians_backward_blend(
                 rs.bg, xyz, radii, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix, rs.projmatrix,
                 rs.tanfovx, rs.tanfovy, grad_out_color, grad_out_depth, grad_out_reps, features_dc, rs.sh_degree,
                 rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.antialiasing, rs.debug, reps,
-                features_rest, True, want_means2D=False)
+                features_rest, True, want_means2D=False, means2D_out=None if slot is None else slot[0])
             # nothing per Gaussian runs here (this may be a side stream with other views' kernels in flight):
             # flush() processes every pending view, however many, in launches of up to eight views
             sink.pending.append(dict(
                 cfg=(float(rs.scale_modifier), int(rs.sh_degree), bool(rs.debug)), viewmatrix=rs.viewmatrix, projmatrix=rs.projmatrix, campos=rs.campos, tanfovx=rs.tanfovx,
                 tanfovy=rs.tanfovy, W=rs.image_width, H=rs.image_height, antialiasing=rs.antialiasing,
                 has_invdepth=grad_out_depth is not None and grad_out_depth.numel() != 0, radii=radii,
-                geom=geomBuffer, work=work, dL_dmeans2D=g_means2D, means2D=ctx.means2D))
+                geom=geomBuffer, work=work, dL_dmeans2D=g_means2D, means2D=ctx.means2D,
+                means2D_blocks=None if slot is None else slot[1]))
             return (None,) * 10
         into, accumulate = None, False
         if sink is not None:
@@ -352,6 +398,7 @@ class _RasterizeGaussiansParams(torch.autograd.Function):
         g_rest = res[9] if len(res) > 9 else None     # a degree-0 model has no second SH tensor
         if sink is not None:
             sink.fresh = False
+            sink.mark_rows_dirty()   # the one-view kernel wrote (or added to) the rows of everything it rendered
             return (None, g_means2D, None, None, None, None, None, None, None, None)
         return (g_means3D, g_means2D, g_dc, g_rest, g_opacity.view_as(opacity), g_scales, g_rot, None,
                 g_reps if reps.numel() != 0 else None, None)

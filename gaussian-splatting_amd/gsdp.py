@@ -263,6 +263,10 @@ def reduce_flush(sink, reducer, chunks=6, after_flush=None):
     if after_flush is not None:
         after_flush()
     reducer.wait()
+    mark = getattr(sink, "mark_rows_dirty", None)
+    active = getattr(reducer, "_active", None)   # a reducer that cannot say is taken to have exchanged
+    if mark is not None and (active is None or active()):
+        mark(rows)   # rows that other ranks reached are non-zero here now (dense: any row may be)
     return mode
 
 

@@ -165,6 +165,15 @@ typedef struct {
                                 dL_drotations, dL_dreps instead of overwriting them (gradient accumulation
                                 over the views of a batch; Gaussians that were not rendered are then not
                                 touched).  dL_dmeans2D, dL_dcolors, dL_dcov3D are always overwritten. */
+    uint8_t* row_blocks;     /* device [(P + 63) / 64] or NULL; gsr_backward_geometry_batch(_range) only.  One byte
+                                per block of 64 consecutive Gaussians, kept by the caller next to PERSISTENT
+                                gradient tensors: 0 = the block's rows of all the parameter gradients above are
+                                zero.  The call does not rewrite such a block with zeros when no view reached one
+                                of its Gaussians (in an occluded scene that is nearly all of its writes), and it
+                                updates the bytes: 1 where it stored gradients, 0 where it stored zeros.  Start
+                                from zeroed tensors and zeroed bytes (or bytes of 1 and any contents), and set the
+                                bytes of rows anything else writes to (a collective that adds other GPUs' rows)
+                                to 1.  NULL: every row is written, as documented above. */
 } GsrBackwardIO;
 
 size_t gsr_geom_bytes(int P);
@@ -208,6 +217,8 @@ typedef struct {
     const void* work;          /* that view's accumulators, filled by gsr_backward_blend */
     float* dL_dmeans2D;        /* device [P,3] or NULL: that view's screen-space gradient, written by the batch call
                                   (then gsr_backward_blend can be given io->dL_dmeans2D = NULL and skips its copy) */
+    uint8_t* means2D_blocks;   /* device [(P + 63) / 64] or NULL: the same bookkeeping as GsrBackwardIO.row_blocks for
+                                  this view's dL_dmeans2D, for callers that keep that tensor from step to step */
 } GsrBackwardView;
 
 int gsr_backward_blend(const GsrScene* scene, const int* radii, const void* geom_buffer, const void* binning_buffer,

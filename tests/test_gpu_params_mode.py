@@ -561,3 +561,91 @@ def test_untouched_rows_have_zero_gradients(defer):
     # the next step starts from an empty record
     sink.begin_step()
     assert not sink.touched_rows().any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunks", [1, 3], ids=["one_launch", "chunked_flush"])
+def test_keep_zero_rows_gives_the_same_gradients(chunks):
+    """ParamGradSink(keep_zero_rows=True): blocks of 64 gradient rows that are zero and stay zero are not
+    rewritten.  Over steps whose views reach different Gaussians the buffers must equal those of a plain
+    sink: exact zeros wherever no view of THAT step reached (nothing stale from an earlier step), the same
+    values elsewhere, the same per-view screen-space gradients; the block states say exactly which blocks
+    hold a reached Gaussian; rows that someone else wrote are cleaned after `mark_rows_dirty`."""
+    from diff_gaussian_rasterization import GaussianRasterizer, ParamGradSink
+    W, H, P = 96, 64, 4000
+    sc = synth.tiny_scene(P=P, width=W, height=H, seed=53)
+    raw = _raw_scene(sc, seed=10)
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda:0")
+    names = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation", "reps")
+    vals = [sc["means3D"], raw["features_dc"], raw["features_rest"], raw["opacity"], raw["scaling"], raw["rotation"],
+            sc["reps"]]
+    settings = _arc_settings(11, W, H)
+    rng = np.random.default_rng(23)
+    ws = [[t(rng.standard_normal(s).astype(np.float32)) for s in ((3, H, W), (1, H, W), (4, H, W))] for _ in range(11)]
+
+    def render(P_, sink, i, m2):
+        o = GaussianRasterizer(settings[i]).forward_params(
+            P_["xyz"], m2, P_["features_dc"], P_["features_rest"], P_["opacity"], P_["scaling"], P_["rotation"],
+            P_["reps"], grad_sink=sink)
+        return o, (o[0] * ws[i][0]).sum() + (o[2] * ws[i][1]).sum() + (o[5] * ws[i][2]).sum()
+
+    # put the Gaussians that some view reaches first, so that whole blocks of 64 are never reached
+    with torch.no_grad():
+        T0 = {n: t(v) for n, v in zip(names, vals)}
+        reached = torch.zeros((P,), dtype=torch.bool, device="cuda:0")
+        for i in range(11):
+            reached |= render(T0, None, i, torch.zeros_like(T0["xyz"]))[0][4] != 0
+    order = torch.argsort((~reached).to(torch.int8), stable=True).cpu().numpy()
+    assert 64 < int(reached.sum()) < P - 256
+    vals = [np.asarray(v)[order] for v in vals]
+    A = {n: t(v).requires_grad_(True) for n, v in zip(names, vals)}
+    B = {n: t(v).requires_grad_(True) for n, v in zip(names, vals)}
+    sink_a = ParamGradSink(*[A[n] for n in names], defer=True)
+    sink_b = ParamGradSink(*[B[n] for n in names], defer=True, keep_zero_rows=True)
+    assert sink_b.row_blocks is not None and sink_a.row_blocks is None
+
+    def step(P_, sink, views):
+        sink.begin_step()
+        m2s, counts = [], []
+        for i in views:
+            m2 = torch.zeros_like(P_["xyz"], requires_grad=True)
+            o, loss = render(P_, sink, i, m2)
+            loss.backward()
+            m2s.append(m2)
+            counts.append(o[4])
+        sink.flush(chunks=chunks)
+        return m2s, torch.stack([c != 0 for c in counts])
+
+    def check(views, label):
+        ma, _ = step(A, sink_a, views)
+        mb, hit = step(B, sink_b, views)
+        torch.cuda.synchronize()
+        want = hit.any(0)
+        for k, g in sink_b.grads.items():
+            g2, r2 = g.view(P, -1), sink_a.grads[k].view(P, -1)
+            assert torch.isfinite(g2).all(), (label, k)
+            assert not g2[~want].any(), (label, k, "stale values in rows no view of this step reached")
+            assert rel_err(g2.cpu().numpy(), r2.cpu().numpy()) <= REL_TOL, (label, k)
+        for v, (x, y) in enumerate(zip(ma, mb)):
+            assert not y.grad[~hit[v]].any(), (label, v)
+            assert rel_err(y.grad.cpu().numpy(), x.grad.cpu().numpy()) <= REL_TOL, (label, v)
+        nb = (P + 63) // 64
+        pad = torch.zeros((nb * 64,), dtype=torch.bool, device="cuda:0")
+        pad[:P] = want
+        assert torch.equal(sink_b.row_blocks.bool(), pad.view(nb, 64).any(1)), label
+        for v, (_, blocks) in enumerate(sink_b.m2_pool[:len(views)]):
+            pad[:P] = hit[v]
+            assert torch.equal(blocks.bool(), pad.view(nb, 64).any(1)), (label, v)
+        return want
+
+    w1 = check([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10], "eleven views: two launches, the second one adds")
+    w2 = check([5], "one view: most of the rows of the first step must be cleared")
+    assert int((w1 & ~w2).sum()) > 0
+    check([0, 10], "two other views")
+    # somebody else writes into rows nobody reaches, and says so
+    rows = torch.tensor([P - 1, P - 70, P - 200], device="cuda:0")
+    for g in sink_b.grads.values():
+        g.view(P, -1)[rows] = 7.0
+    sink_b.mark_rows_dirty(rows)
+    check([3, 4], "after foreign writes")
+    assert len(sink_b.m2_pool) == 11
