@@ -118,8 +118,9 @@ class KernelTimer:
     PAIRS = {"preprocess": (0, 1), "scan": (1, 2), "host_sync_gap": (2, 3), "tile_count": (3, 18), "depth_order": (18, 4), "emit_keys": (4, 5), "sort": (5, 6),
              "tile_ranges": (6, 7), "render_fwd": (7, 8), "finish_stats": (8, 9), "bwd_clear": (10, 11),
              "render_bwd": (11, 12), "preprocess_bwd": (12, 13), "preprocess_bwd_batch": (14, 15),
-             "preprocess_batch": (16, 17)}
-    PER_STEP = ("preprocess_bwd_batch", "preprocess_batch")   # one launch per step, recorded in one event set of it
+             "preprocess_batch": (16, 17), "depth_order_batch": (19, 20)}
+    # one launch (one set of launches) per step, recorded in one event set of it
+    PER_STEP = ("preprocess_bwd_batch", "preprocess_batch", "depth_order_batch")
 
     def __init__(self, sets):
         import _gsplat_lib as G
@@ -169,6 +170,7 @@ def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1, walked=None, from_
     return {
         "preprocess": 315.0 * visible + 20.0 * (P - visible),
         "depth_order": P * (16.0 + 8.0 + 4.0 + 4 * 16.0),       # bin read, pair write, histogram read, 4 passes
+        "depth_order_batch": V * P * (16.0 + 8.0 + 4.0 + 4 * 16.0),   # the same for the V views of a step in shared launches
         "emit_keys": P * (4.0 + 16.0 + 16.0 + 16.0) + 8.0 * R,  # gather + sbin write + sbin read, pair write
         # the digit histograms and the tile ranges come from the tile rectangles (16 B per Gaussian) when the
         # tile grid fits one workgroup's LDS; otherwise from a histogram sweep and a range scan over the keys
@@ -192,7 +194,7 @@ def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1, walked=None, from_
 
 # What bounds each kernel (the blend kernels stop early per pixel and are limited by
 # VALU / LDS issue, not by the bytes they move; the others stream through HBM).
-BOUND = {"tile_count": "hbm", "preprocess_bwd_batch": "hbm", "preprocess_batch": "hbm", "preprocess": "hbm", "depth_order": "hbm", "emit_keys": "hbm", "sort": "hbm", "tile_ranges": "hbm",
+BOUND = {"tile_count": "hbm", "preprocess_bwd_batch": "hbm", "preprocess_batch": "hbm", "preprocess": "hbm", "depth_order": "hbm", "depth_order_batch": "hbm", "emit_keys": "hbm", "sort": "hbm", "tile_ranges": "hbm",
          "render_fwd": "valu+lds", "render_bwd": "valu+lds+atomics", "preprocess_bwd": "hbm"}
 
 
@@ -831,8 +833,8 @@ def main():
             # here by the depth ordering of the Gaussians, the emission that partitions on the high tile digit and
             # the segmented pass on the low one: payload rate R x 12 B over ALL of that (emission included: a
             # lower bound for the sort alone).  `sort_u64` (extras) is the stand-alone 64-bit sort of the C ABI.
-            "sort_GBps": (R * 12.0 / ((kernels["sort"] + kernels["depth_order"] + kernels["emit_keys"]) * 1e-3) / 1e9)
-                         if R else None,
+            "sort_GBps": (R * 12.0 / ((kernels["sort"] + kernels["depth_order"] + kernels.get("depth_order_batch", 0.0) / V +
+                                       kernels["emit_keys"]) * 1e-3) / 1e9) if R else None,
             "sort_hbm_GBps": (algorithmic_bytes("sort", P, visible, R, H * W, passes, V, walked, from_rects) /
                               (kernels["sort"] * 1e-3) / 1e9) if R else None,
         }

@@ -48,7 +48,8 @@ class GsrBackwardView(C.Structure):
 class GsrForwardView(C.Structure):
     _fields_ = [("viewmatrix", _vp), ("projmatrix", _vp), ("campos", _vp), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
                 ("W", C.c_int), ("H", C.c_int), ("antialiasing", C.c_int), ("radii", _vp), ("out_depths", _vp),
-                ("geom_buffer", _vp), ("geom_bytes", C.c_size_t), ("num_rendered", C.c_int64), ("num_visible", C.c_int64)]
+                ("geom_buffer", _vp), ("geom_bytes", C.c_size_t), ("num_rendered", C.c_int64), ("num_visible", C.c_int64),
+                ("depth_ordered", C.c_int)]
 
 
 class GsrLayout(C.Structure):
@@ -169,7 +170,7 @@ EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backw
             "gso_gather_rows", "gsr_status_string")
 
 
-NUM_PROFILE_EVENTS = 19
+NUM_PROFILE_EVENTS = 21
 EVENT_NAMES = ("stage1_begin", "preprocess", "scan", "stage2_begin", "depth_order", "emit", "sort", "ranges", "render",
                "finish", "bwd_begin", "bwd_clear", "bwd_render", "bwd_preprocess", "batch_begin", "batch",
                "fwd_batch_begin", "fwd_batch", "tile_count")

@@ -143,8 +143,9 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
         }
         mark(s, GSR_EV_TILE_COUNT, st);
         if (R > 0) {
-            int ord = 0;
-            GSR_TRY(launch_depth_order(g, s->P, n, st, &ord));
+            int ord = 0;   // gsr_preprocess_batch leaves the order it made in buffer 0
+            const bool ordered = o->preprocessed == 2 && o->num_visible > 0 && o->num_visible <= s->P;
+            if (!ordered) GSR_TRY(launch_depth_order(g, s->P, n, st, &ord));
             mark(s, GSR_EV_DEPTH_ORDER, st);
             if (fused) {
                 GSR_TRY(launch_order_gather(g, g.dvals[ord], n, st));
@@ -297,6 +298,7 @@ int gsr_preprocess_batch(const GsrScene* s, int nviews, GsrForwardView* views, v
     for (int v = 0; v < nviews; ++v) {
         GsrForwardView& fv = views[v];
         fv.num_rendered = fv.num_visible = 0;
+        fv.depth_ordered = 0;
         if (!fv.viewmatrix || !fv.projmatrix || !fv.campos || !fv.radii || !fv.out_depths || !fv.geom_buffer ||
             fv.W <= 0 || fv.H <= 0 || fv.W > 65535 * TILE_X || fv.H > 65535 * TILE_Y)
             return GSR_ERR_ARG;
@@ -325,6 +327,27 @@ int gsr_preprocess_batch(const GsrScene* s, int nviews, GsrForwardView* views, v
             views[v0 + k].num_visible = (int64_t)tot[k][2];
         }
     }
+#ifndef GS_NO_BATCH_DEPTH_ORDER
+    // the front-to-back orders of the views that have instances, up to SORT_BATCH_MAX views per set of launches
+    mark(s, GSR_EV_FWD_BATCH_SORT_BEGIN, st);
+    for (int v0 = 0; v0 < nviews;) {
+        GeomBuf gb[SORT_BATCH_MAX];
+        int nvis[SORT_BATCH_MAX], which[SORT_BATCH_MAX], m = 0;
+        for (; v0 < nviews && m < SORT_BATCH_MAX; ++v0) {
+            const GsrForwardView& fv = views[v0];
+            if (fv.num_rendered <= 0 || fv.num_visible <= 0 || fv.num_visible > s->P ||
+                sort_status_wide((size_t)fv.num_visible))
+                continue;
+            gb[m] = geom_buf(fv.geom_buffer, (size_t)s->P);
+            nvis[m] = (int)fv.num_visible;
+            which[m++] = v0;
+        }
+        if (m == 0) continue;
+        GSR_TRY(launch_depth_order_batch(m, gb, s->P, nvis, st));
+        for (int k = 0; k < m; ++k) views[which[k]].depth_ordered = 1;
+    }
+    mark(s, GSR_EV_FWD_BATCH_SORT, st);
+#endif
     return GSR_OK;
 }
 

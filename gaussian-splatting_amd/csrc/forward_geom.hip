@@ -413,8 +413,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* sum
 // Depth keys for ordering the Gaussians front to back: the f32 bits of the
 // view-space depth (positive floats order like their bit patterns), all ones
 // for Gaussians that produce no instance so that they sort to the end.
-__global__ void __launch_bounds__(PRE_BLOCK) depth_keys_kernel(int P, const uint2* dt, const uint32_t* vis_off,
-                                                               uint32_t* keys, uint32_t* vals) {
+__device__ __forceinline__ void depth_keys_body(int P, const uint2* dt, const uint32_t* vis_off, uint32_t* keys,
+                                                uint32_t* vals) {
     // vis_off == null: one pair per Gaussian (those without instances get the largest key).
     // Otherwise only Gaussians with instances get a pair, packed in index order: a block's pairs
     // start at vis_off[block] (blocks = the preprocess blocks that counted them).
@@ -439,6 +439,23 @@ __global__ void __launch_bounds__(PRE_BLOCK) depth_keys_kernel(int P, const uint
         keys[dst] = b.x;
         vals[dst] = (uint32_t)i;
     }
+}
+
+__global__ void __launch_bounds__(PRE_BLOCK) depth_keys_kernel(int P, const uint2* dt, const uint32_t* vis_off,
+                                                               uint32_t* keys, uint32_t* vals) {
+    depth_keys_body(P, dt, vis_off, keys, vals);
+}
+
+struct DepthKeysBatch {   // blockIdx.y = view
+    const uint2* dt[SORT_BATCH_MAX];
+    const uint32_t* vis_off[SORT_BATCH_MAX];
+    uint32_t* keys[SORT_BATCH_MAX];
+    uint32_t* vals[SORT_BATCH_MAX];
+};
+
+__global__ void __launch_bounds__(PRE_BLOCK) depth_keys_batch_kernel(int P, const DepthKeysBatch b) {
+    const int v = blockIdx.y;
+    depth_keys_body(P, b.dt[v], b.vis_off[v], b.keys[v], b.vals[v]);
 }
 
 // The tile rectangles in depth order: sbin[i] = {rect origin, rect size, Gaussian
@@ -793,6 +810,28 @@ hipError_t launch_depth_order(const GeomBuf& g, int P, int n, hipStream_t st, in
     uint32_t* k[2] = {g.dkeys[0], g.dkeys[1]};
     uint32_t* v[2] = {g.dvals[0], g.dvals[1]};
     return launch_radix_sort_u32(k, v, n, 0, 32, g.dsort_temp, st, order_buffer, false);
+}
+
+hipError_t launch_depth_order_batch(int count, const GeomBuf* g, int P, const int* n, hipStream_t st) {
+    if (count <= 0 || P <= 0) return hipSuccess;
+    if (count > SORT_BATCH_MAX) return hipErrorInvalidValue;
+    DepthKeysBatch b;
+    uint32_t* keys[SORT_BATCH_MAX][2];
+    uint32_t* vals[SORT_BATCH_MAX][2];
+    int64_t n64[SORT_BATCH_MAX];
+    void* temp[SORT_BATCH_MAX];
+    for (int i = 0; i < count; ++i) {
+        b.dt[i] = g[i].dt;
+        b.vis_off[i] = n[i] < P ? g[i].vis_sums : (const uint32_t*)nullptr;
+        b.keys[i] = g[i].dkeys[0];
+        b.vals[i] = g[i].dvals[0];
+        keys[i][0] = g[i].dkeys[0]; keys[i][1] = g[i].dkeys[1];
+        vals[i][0] = g[i].dvals[0]; vals[i][1] = g[i].dvals[1];
+        n64[i] = n[i];
+        temp[i] = g[i].dsort_temp;
+    }
+    hipLaunchKernelGGL(depth_keys_batch_kernel, dim3((P + PRE_BLOCK - 1) / PRE_BLOCK, count), dim3(PRE_BLOCK), 0, st, P, b);
+    return launch_radix_sort_u32_batch(count, keys, vals, n64, temp, st);
 }
 
 hipError_t launch_order_gather(const GeomBuf& g, const uint32_t* order, int n, hipStream_t st) {

@@ -396,6 +396,7 @@ inline ImageView image_view(void* base, size_t W, size_t H) {
 #endif
 constexpr int SORT_TILE = GS_SORT_TILE;   // keys per onesweep workgroup
 constexpr int SORT_MAX_PASSES = 8;
+constexpr int SORT_BATCH_MAX = 8;         // independent sorts that share the launches of launch_radix_sort_u32_batch
 
 // The key bits are dealt evenly to the passes (13 bits: 7 + 6, not 8 + 5): the fewer buckets a
 // pass has, the longer the contiguous run a tile writes into each of them.

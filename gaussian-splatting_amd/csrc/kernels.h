@@ -77,6 +77,9 @@ hipError_t launch_scan_blocks(const GeomBuf& g, int nb, hipStream_t st);
 // Depth keys of the n Gaussians to order (n = number with instances: compacted; n = P: all of them),
 // sorted front to back (stable): g.dvals[*order_buffer][0..n) is the order.
 hipError_t launch_depth_order(const GeomBuf& g, int P, int n, hipStream_t st, int* order_buffer);
+// The same for up to SORT_BATCH_MAX views of the same P Gaussians in shared launches (n[i] as above, each
+// below 2^30); every view's order ends in its g.dvals[0].
+hipError_t launch_depth_order_batch(int count, const GeomBuf* g, int P, const int* n, hipStream_t st);
 // Key emission in depth order: (tile id, Gaussian index) pairs; only the tile remains to be sorted on.
 hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, const uint32_t* order, int n, uint32_t* keys,
                             uint32_t* vals, hipStream_t st);
@@ -120,6 +123,8 @@ hipError_t launch_emit_partition(const GeomBuf& g, int n_visible, int grid_x, in
 hipError_t launch_segmented_pass(int n_visible, int ntiles, int nbits, int64_t R, const uint2* ranges, uint32_t* keys[2],
                                  uint32_t* vals[2], void* temp, hipStream_t st);
 // The same with 32-bit keys.  hist_ready: the digit histograms in the temp area were filled by the caller.
+hipError_t launch_radix_sort_u32_batch(int count, uint32_t* const (*keys)[2], uint32_t* const (*vals)[2], const int64_t* n,
+                                       void* const* temp, hipStream_t st);
 hipError_t launch_radix_sort_u32(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit,
                                  void* temp, hipStream_t st, int* result_buffer, bool hist_ready);
 

@@ -42,9 +42,10 @@ int sort_passes_for(int begin_bit, int end_bit) { return (end_bit - begin_bit + 
 
 // Digit histograms of all passes in one read of the keys, 16 bytes per lane and load (a lane
 // that reads one key per trip spends its time waiting for that load).
+// (nblocks workgroups, numbered blockIdx.x = 0 .. nblocks - 1, share the keys)
 template <class K>
-__global__ void __launch_bounds__(256) sort_hist_kernel(const K* keys, int64_t n, int passes, int begin_bit,
-                                                        int end_bit, uint32_t* ghist) {
+__device__ __forceinline__ void sort_hist_body(const K* keys, int64_t n, int passes, int begin_bit, int end_bit,
+                                               uint32_t* ghist, int nblocks) {
     constexpr int V = 16 / sizeof(K);
     __shared__ uint32_t h[SORT_MAX_PASSES * 256];
     for (int i = threadIdx.x; i < passes * 256; i += 256) h[i] = 0;
@@ -55,7 +56,7 @@ __global__ void __launch_bounds__(256) sort_hist_kernel(const K* keys, int64_t n
         for (int p = 0; p < passes; ++p)
             atomicAdd(&h[p * 256 + ((uint32_t)(k >> (begin_bit + shift[p])) & ((1u << bits[p]) - 1))], 1u);
     };
-    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t stride = (int64_t)nblocks * 256;
     const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     // whole 16-byte groups when the array starts on a 16-byte boundary, single keys otherwise and for the rest
     const int64_t nvec = (reinterpret_cast<uintptr_t>(keys) & 15) == 0 ? n / V : 0;
@@ -88,10 +89,49 @@ __global__ void __launch_bounds__(256) sort_hist_kernel(const K* keys, int64_t n
     }
 }
 
+template <class K>
+__global__ void __launch_bounds__(256) sort_hist_kernel(const K* keys, int64_t n, int passes, int begin_bit,
+                                                        int end_bit, uint32_t* ghist) {
+    sort_hist_body<K>(keys, n, passes, begin_bit, end_bit, ghist, (int)gridDim.x);
+}
+
+// Several independent sorts of u32 pairs in one grid (blockIdx.y = which): the depth orders of the views
+// of a batch, each of which alone is a single wave of workgroups that waits on its look-back chain.
+struct SortBatchArgs {
+    const uint32_t* kin[SORT_BATCH_MAX];
+    const uint32_t* vin[SORT_BATCH_MAX];
+    uint32_t* kout[SORT_BATCH_MAX];
+    uint32_t* vout[SORT_BATCH_MAX];
+    int64_t n[SORT_BATCH_MAX];
+    uint32_t* ghist[SORT_BATCH_MAX];    // this pass's 256 bins (all passes' bins for the histogram kernels)
+    uint32_t* status[SORT_BATCH_MAX];   // this pass's look-back words
+    uint32_t* ticket[SORT_BATCH_MAX];
+    uint32_t* err[SORT_BATCH_MAX];
+};
+
+__global__ void __launch_bounds__(256) sort_hist_batch_kernel(const SortBatchArgs b, int passes, int begin_bit,
+                                                              int end_bit) {
+    const int v = blockIdx.y;
+    // the grid is sized for the longest array: an array is shared by as many workgroups as it has tiles
+    const int64_t tiles = (b.n[v] + SORT_TILE - 1) / SORT_TILE;
+    const int nblocks = (int)(tiles < (int64_t)gridDim.x ? tiles : (int64_t)gridDim.x);
+    if ((int)blockIdx.x >= nblocks) return;
+    sort_hist_body<uint32_t>(b.kin[v], b.n[v], passes, begin_bit, end_bit, b.ghist[v], nblocks);
+}
+
 // Exclusive scan of each pass's 256-bin histogram, in place.
 __global__ void __launch_bounds__(256) sort_scan_hist_kernel(uint32_t* ghist) {
     __shared__ uint32_t s_tmp[8];
     uint32_t* h = ghist + blockIdx.x * 256;
+    uint32_t total;
+    const uint32_t ex = block_scan_excl_256(h[threadIdx.x], s_tmp, &total);
+    h[threadIdx.x] = ex;
+}
+
+__global__ void __launch_bounds__(256) sort_scan_hist_batch_kernel(const SortBatchArgs b) {
+    __shared__ uint32_t s_tmp[8];
+    if (b.n[blockIdx.y] <= 0) return;   // left out: no histogram
+    uint32_t* h = b.ghist[blockIdx.y] + blockIdx.x * 256;
     uint32_t total;
     const uint32_t ex = block_scan_excl_256(h[threadIdx.x], s_tmp, &total);
     h[threadIdx.x] = ex;
@@ -136,10 +176,10 @@ struct SegArgs {
 };
 
 template <class K, int THREADS, int ITEMS, int BITS, bool SEG, class S = uint32_t>
-__global__ void __launch_bounds__(THREADS, (GS_OS_BLOCKS * THREADS) / 256)
-onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __restrict__ kout,
-                uint32_t* __restrict__ vout, int64_t n, int shift, int bits, const uint32_t* __restrict__ gbase,
-                S* status, uint32_t* ticket, uint32_t* err, const SegArgs seg) {
+__device__ __forceinline__ void onesweep_tile(const K* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                              K* __restrict__ kout, uint32_t* __restrict__ vout, int64_t n, int shift,
+                                              int bits, const uint32_t* __restrict__ gbase, S* status, uint32_t* ticket,
+                                              uint32_t* err, const SegArgs& seg) {
     constexpr int NW = THREADS / 64;
     constexpr int TILE = THREADS * ITEMS;
     constexpr bool ONE_PHASE = sizeof(K) == 4;  // keys and values fit the staging area together
@@ -335,6 +375,26 @@ onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* 
         const uint32_t pos = tid + k * THREADS;
         if (pos < tile_n) vout[dst[k]] = s_vals[pos];
     }
+}
+
+template <class K, int THREADS, int ITEMS, int BITS, bool SEG, class S = uint32_t>
+__global__ void __launch_bounds__(THREADS, (GS_OS_BLOCKS * THREADS) / 256)
+onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __restrict__ kout,
+                uint32_t* __restrict__ vout, int64_t n, int shift, int bits, const uint32_t* __restrict__ gbase,
+                S* status, uint32_t* ticket, uint32_t* err, const SegArgs seg) {
+    onesweep_tile<K, THREADS, ITEMS, BITS, SEG, S>(kin, vin, kout, vout, n, shift, bits, gbase, status, ticket, err, seg);
+}
+
+// One pass of several independent sorts (see SortBatchArgs).  Exactly ceil(n / tile) workgroups of a sort
+// go on and take its tickets, so that its tile numbers stay inside its status words.
+template <int THREADS, int ITEMS>
+__global__ void __launch_bounds__(THREADS, (GS_OS_BLOCKS * THREADS) / 256)
+onesweep_batch_kernel(const SortBatchArgs b, int shift, int bits) {
+    const int v = blockIdx.y;
+    const int64_t n = b.n[v];
+    if ((int64_t)blockIdx.x * (THREADS * ITEMS) >= n) return;
+    onesweep_tile<uint32_t, THREADS, ITEMS, 8, false, uint32_t>(b.kin[v], b.vin[v], b.kout[v], b.vout[v], n, shift, bits,
+                                                                 b.ghist[v], b.status[v], b.ticket[v], b.err[v], SegArgs());
 }
 
 // ------------------------------------------------------------------ key emission that partitions
@@ -669,6 +729,56 @@ hipError_t radix_sort_impl(K* keys[2], uint32_t* vals[2], int64_t n, int begin_b
         cur ^= 1;
     }
     *result_buffer = cur;
+    return hipGetLastError();
+}
+
+// Up to SORT_BATCH_MAX stable sorts of u32 pairs on all 32 key bits, pass by pass in shared launches; every
+// result ends in keys[0] / vals[0] (four passes).  Arrays of at most 2^30 pairs; n[i] <= 0 leaves sort i out.
+hipError_t launch_radix_sort_u32_batch(int count, uint32_t* const (*keys)[2], uint32_t* const (*vals)[2], const int64_t* n,
+                                       void* const* temp, hipStream_t st) {
+    if (count <= 0) return hipSuccess;
+    if (count > SORT_BATCH_MAX) return hipErrorInvalidValue;
+    constexpr int passes = 4;
+    static_assert(passes % 2 == 0, "the result must end in buffer 0");
+    SortBatchArgs b = SortBatchArgs();
+    SortTemp t[SORT_BATCH_MAX];
+    int64_t tiles[SORT_BATCH_MAX], max_tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        b.n[i] = n[i] > 0 ? n[i] : 0;
+        tiles[i] = (b.n[i] + SORT_TILE - 1) / SORT_TILE;
+        if (tiles[i] == 0) continue;
+        if (sort_status_wide((size_t)b.n[i])) return hipErrorInvalidValue;
+        t[i] = sort_temp_view(temp[i], (size_t)b.n[i], passes);
+        hipError_t e = hipMemsetAsync(t[i].ghist, 0, t[i].zero_bytes, st);
+        if (e != hipSuccess) return e;
+        if (tiles[i] > max_tiles) max_tiles = tiles[i];
+        b.kin[i] = keys[i][0];
+        b.ghist[i] = t[i].ghist;
+    }
+    if (max_tiles == 0) return hipSuccess;
+    const unsigned hist_blocks = (unsigned)(max_tiles < 2048 ? max_tiles : 2048);
+    hipLaunchKernelGGL(sort_hist_batch_kernel, dim3(hist_blocks, count), dim3(256), 0, st, b, passes, 0, 32);
+    hipLaunchKernelGGL(sort_scan_hist_batch_kernel, dim3(passes, count), dim3(256), 0, st, b);
+    auto kern = onesweep_batch_kernel<OS_THREADS, OS_ITEMS>;
+    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)OS_LDS);
+    if (ea != hipSuccess) return ea;
+    int cur = 0;
+    for (int p = 0; p < passes; ++p) {
+        int shift, bits;
+        digit_of_pass(32, passes, p, &shift, &bits);
+        for (int i = 0; i < count; ++i) {
+            if (tiles[i] == 0) continue;
+            b.kin[i] = keys[i][cur]; b.vin[i] = vals[i][cur];
+            b.kout[i] = keys[i][cur ^ 1]; b.vout[i] = vals[i][cur ^ 1];
+            b.ghist[i] = t[i].ghist + p * 256;
+            b.status[i] = (uint32_t*)t[i].status + (size_t)p * tiles[i] * 256;
+            b.ticket[i] = t[i].ticket + p;
+            b.err[i] = t[i].err;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)max_tiles, count), dim3(OS_THREADS), OS_LDS, st, b, shift, bits);
+        cur ^= 1;
+    }
     return hipGetLastError();
 }
 

@@ -134,7 +134,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         o.last_contr_gauss, o.out_depths, o.out_reps = ptr(last_contr), ptr(out_depths), ptr(out_reps)
         o.geom_buffer, o.geom_bytes = ptr(geom), geom.numel()
         o.image_buffer, o.image_bytes = ptr(img), img.numel()
-        o.preprocessed = 1 if prepared else 0
+        o.preprocessed = (2 if prepared.get("depth_ordered") else 1) if prepared else 0
         st = stream_of(dev)
         if prepared and "num_rendered" in prepared:   # the batch call has run the prefix sums too
             R = int(prepared["num_rendered"])
@@ -384,6 +384,7 @@ def preprocess_batch(means3D, opacities, scales, rotations, scale_modifier, sh, 
             check(L.gsr_preprocess_batch(C.byref(s), len(views), arr, stream_of(dev)), "preprocess_batch")
         for k, d in enumerate(out):
             d["num_rendered"], d["num_visible"] = int(arr[k].num_rendered), int(arr[k].num_visible)
+            d["depth_ordered"] = bool(arr[k].depth_ordered)
     return out
 
 

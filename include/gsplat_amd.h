@@ -110,7 +110,9 @@ typedef enum {
     GSR_EV_FWD_BATCH_BEGIN = 16,
     GSR_EV_FWD_BATCH = 17,     /* preprocess of a batch of views (gsr_preprocess_batch) */
     GSR_EV_TILE_COUNT = 18,    /* tile ranges and sort histograms from the tile rectangles (after STAGE2_BEGIN, before the depth order) */
-    GSR_NUM_PROFILE_EVENTS = 19
+    GSR_EV_FWD_BATCH_SORT_BEGIN = 19,
+    GSR_EV_FWD_BATCH_SORT = 20,/* front-to-back orders of the views of a batch (gsr_preprocess_batch, after its host block) */
+    GSR_NUM_PROFILE_EVENTS = 21
 } GsrProfileEvent;
 
 /* Outputs of the forward pass.  None of them needs initialising by the caller. */
@@ -132,7 +134,10 @@ typedef struct {
                                 that produce at least one instance; stage 2 orders only those by depth.  A value
                                 < 0 there means "not known" and all P are ordered. */
     int preprocessed;        /* nonzero: geom_buffer, radii and out_depths were filled by gsr_preprocess_batch for
-                                this view; gsr_forward_stage1 then only runs the prefix sums */
+                                this view; gsr_forward_stage1 then only runs the prefix sums.  2 (only where
+                                gsr_preprocess_batch reported GsrForwardView.depth_ordered, and with that call's
+                                num_visible): the geometry buffer also holds the view's front-to-back order of
+                                the Gaussians, and gsr_forward_stage2 does not sort them again */
     uint32_t* sort_error_host; /* NULL, or a word of host memory that the GPU can write (hipHostMalloc / pinned):
                                 the last kernel of gsr_forward_stage2 stores the radix sort's error word there, in
                                 stream order and without making the call wait.  Nonzero = a look-back did not
@@ -239,8 +244,9 @@ int gsr_backward_geometry_batch_range(const GsrScene* scene, int nviews, const G
  * what the preprocess of gsr_forward_stage1 would (bit for bit), except the 3D covariance, which the
  * backward recomputes.  It also runs the prefix sums of every view and, blocking the host once for
  * all of them, returns each view's instance count in num_rendered / num_visible: the views can go
- * straight to gsr_forward_stage2 (GsrForwardOut.preprocessed = 1, num_visible copied over, the same
- * three buffers), so a step of V views blocks the host once instead of V times.
+ * straight to gsr_forward_stage2 (GsrForwardOut.preprocessed = 1, or 2 where depth_ordered was reported,
+ * num_visible copied over, the same three buffers), so a step of V views blocks the host once instead of
+ * V times.
  * (gsr_forward_stage1 with preprocessed = 1 is also allowed: it repeats the sums and the copy.)
  * Needs the SH tensors split (scene->shs_rest), M == 16 and scales + rotations; the camera fields,
  * W, H and antialiasing of `scene` are ignored (each view brings its own).  Returns
@@ -258,6 +264,10 @@ typedef struct {
     size_t geom_bytes;
     int64_t num_rendered;      /* out (host): (Gaussian, tile) instances of this view */
     int64_t num_visible;       /* out (host): Gaussians of this view with at least one instance */
+    int depth_ordered;         /* out (host): nonzero = the call also ordered this view's Gaussians front to back (the
+                                  depth sorts of up to eight views share their launches: a view's own sort is a
+                                  single wave of workgroups waiting on its look-back chain); pass
+                                  GsrForwardOut.preprocessed = 2 to gsr_forward_stage2 then */
 } GsrForwardView;
 int gsr_preprocess_batch(const GsrScene* scene, int nviews, GsrForwardView* views, void* stream);
 

@@ -333,6 +333,7 @@ def test_batched_forward_preprocess_is_bit_identical(nviews, P):
         b = fwd(rs, pr)
         torch.cuda.synchronize()
         assert a["num_rendered"] == b["num_rendered"]
+        assert pr["depth_ordered"] == (a["num_rendered"] > 0)   # the batch call also made the front-to-back order
         seen_any += a["num_rendered"]
         vis = a["radii"].cpu().numpy() > 0
         for k in ("color", "radii", "invdepth", "accum_alpha", "gauss_count", "last_contr_gauss", "out_reps"):

@@ -18,7 +18,9 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "pmc")
 KERNEL_KEYS = {  # kernel symbol substring -> bench.py kernel name
-    "preprocess_fwd_kernel": "preprocess", "depth_keys_kernel": "depth_order:keys", 
+    "depth_keys_batch_kernel": "depth_order_batch:keys", "sort_hist_batch_kernel": "depth_order_batch:hist",
+    "sort_scan_hist_batch_kernel": "depth_order_batch:scan", "onesweep_batch_kernel": "depth_order_batch:onesweep",
+    "preprocess_fwd_kernel": "preprocess", "depth_keys_kernel": "depth_order:keys",
     "emit_keys_kernel": "emit_keys", "onesweep_kernel": "sort:onesweep", "sort_hist_kernel": "sort:hist",
     "sort_scan_hist_kernel": "sort:scan", "tile_ranges_kernel": "tile_ranges", "render_fwd_kernel": "render_fwd",
     "render_bwd_kernel": "render_bwd", "preprocess_bwd_kernel": "preprocess_bwd",
@@ -45,6 +47,9 @@ COMPOSED = {
     "tile_count": (("tile_count:count", 1), ("tile_count:finish", 1)),
     "depth_order": (("depth_order:keys", 1), ("depth_order:hist", 1), ("depth_order:onesweep", 4)),
     "emit_keys": (("depth_order:gather", 1), ("emit_keys", 1)),
+    # per step: the depth orders of all its views in shared launches
+    "depth_order_batch": (("depth_order_batch:keys", 1), ("depth_order_batch:hist", 1), ("depth_order_batch:scan", 1),
+                          ("depth_order_batch:onesweep", 4)),
 }
 
 
