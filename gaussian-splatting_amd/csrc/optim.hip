@@ -199,10 +199,15 @@ __global__ void __launch_bounds__(256) mark_nonzero_kernel(const MarkArgs a) {
     if (i0 >= a.N) return;
     if (i0 + 4 <= a.N) {
         uint32_t m = a.accumulate ? *reinterpret_cast<const uint32_t*>(a.mask + i0) : 0u;
-        for (int v = 0; v < a.n; ++v) {
-            const int4 c = *reinterpret_cast<const int4*>(a.counts[v] + i0);
-            m |= (c.x != 0 ? 1u : 0u) | (c.y != 0 ? 1u << 8 : 0u) | (c.z != 0 ? 1u << 16 : 0u) | (c.w != 0 ? 1u << 24 : 0u);
-        }
+        // all the arrays' loads first (the launcher repeats the first array in the unused slots): a loop over
+        // a run-time count would wait for each load before issuing the next
+        int4 c[MARK_MAX_ARRAYS];
+#pragma unroll
+        for (int v = 0; v < MARK_MAX_ARRAYS; ++v) c[v] = *reinterpret_cast<const int4*>(a.counts[v] + i0);
+#pragma unroll
+        for (int v = 0; v < MARK_MAX_ARRAYS; ++v)
+            m |= (c[v].x != 0 ? 1u : 0u) | (c[v].y != 0 ? 1u << 8 : 0u) | (c[v].z != 0 ? 1u << 16 : 0u) |
+                 (c[v].w != 0 ? 1u << 24 : 0u);
         *reinterpret_cast<uint32_t*>(a.mask + i0) = m;
     } else {
         for (int64_t i = i0; i < a.N; ++i) {
@@ -272,7 +277,7 @@ hipError_t launch_mark_nonzero(int64_t N, int n, const int* const* counts, uint8
     for (int first = 0; first < n; first += MARK_MAX_ARRAYS) {
         MarkArgs a;
         a.n = n - first < MARK_MAX_ARRAYS ? n - first : MARK_MAX_ARRAYS;
-        for (int v = 0; v < a.n; ++v) a.counts[v] = counts[first + v];
+        for (int v = 0; v < MARK_MAX_ARRAYS; ++v) a.counts[v] = counts[first + (v < a.n ? v : 0)];   // every slot is read
         a.accumulate = first > 0;
         a.N = N;
         a.mask = mask;

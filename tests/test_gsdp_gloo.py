@@ -219,6 +219,9 @@ def _sparse_worker(rank, world, port, out_dir):
         sink, leaves = _make_fake_sink(params)
         sink.begin_step()
         sink.flat.fill_(float("nan"))
+        # the bookkeeping of keep_zero_rows (the stand-in kernels do not keep it: what shows afterwards is what
+        # the exchange reported as written by other ranks)
+        sink.row_blocks = torch.zeros(((1000 + 63) // 64,), dtype=torch.uint8)
         for vi in gsdp.shard_views(5, rank, world):
             sink.pending.append(dict(cfg=(1.0, 3, False), w=views[vi], means2D=torch.zeros(3, requires_grad=True),
                                      dL_dmeans2D=torch.ones(3)))
@@ -228,7 +231,7 @@ def _sparse_worker(rank, world, port, out_dir):
             red.mask_as_bytes = False     # the row masks as int32 with SUM, for backends without 8-bit MAX
         took = gsdp.reduce_flush(sink, red, chunks=3)
         out[name] = dict(grads=[p.grad.clone() for p in leaves], took=took, union=red.last_union,
-                         launches=len(sink.launches))
+                         launches=len(sink.launches), dirty_blocks=sink.row_blocks.clone())
         type(sink).launches.clear()
     # three dense steps in a row: the fourth one does not probe (no mask exchange), the 16th plan does
     red = gsdp.GradReducer(sparse="auto", probe_every=4)
@@ -262,9 +265,15 @@ def test_sparse_row_exchange_world2(tmp_path):
             for g, k in zip(got[name]["grads"], order):
                 ref = sum(_view_grad(params[k], v) for v in views)
                 assert torch.allclose(g, ref, rtol=1e-5, atol=1e-6), (name, k, r)
+            touched = torch.stack([v.ne(0) for v in views]).any(0)
             if name != "never":
-                union = int(torch.stack([v.ne(0) for v in views]).any(0).sum())
-                assert tuple(got[name]["union"]) == (union, 1000)
+                assert tuple(got[name]["union"]) == (int(touched.sum()), 1000)
+            # rows that other ranks made non-zero are reported to the sink: the union's blocks of 64 after a
+            # sparse exchange, every block after a dense one
+            pad = torch.zeros((16 * 64,), dtype=torch.bool)
+            pad[:1000] = touched
+            want = pad.view(16, 64).any(1) if took == "sparse" else torch.ones((16,), dtype=torch.bool)
+            assert torch.equal(got[name]["dirty_blocks"].bool(), want), name
         # the sparse path flushes in one launch, the dense one in three ranges
         assert got["sparse_auto"]["launches"] == 1 and got["dense_auto"]["launches"] == 3
         # 8 plans with probe_every 4: plans 1-3 probe (streak builds), then only plans 4 and 8
