@@ -156,6 +156,13 @@ def lib():
     L.gso_gather_rows.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_int, _vp]
     L.gsr_status_string.restype = C.c_char_p
     L.gsr_status_string.argtypes = [C.c_int]
+    L.gsr_struct_bytes.restype = C.c_size_t
+    L.gsr_struct_bytes.argtypes = [C.c_int]
+    # the structures above mirror include/gsplat_amd.h field by field: a library built from another header fails here
+    for which, cls in enumerate((GsrScene, GsrForwardOut, GsrBackwardIO, GsrBackwardView, GsrForwardView, GsrLayout)):
+        if L.gsr_struct_bytes(which) != C.sizeof(cls):
+            raise RuntimeError(f"{LIB_PATH}: {cls.__name__} is {L.gsr_struct_bytes(which)} bytes in the library and "
+                               f"{C.sizeof(cls)} in this binding (rebuild the library: make -C csrc)")
     _lib = L
     return L
 
@@ -167,13 +174,13 @@ EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backw
             "gss_ssim_backward", "gss_loss_partial_floats", "gss_l1_ssim_loss_forward", "gss_l1_ssim_loss_backward",
             "gss_l1_partial_floats", "gss_l1_loss_forward", "gss_l1_loss_backward",
             "gso_adam_update", "gso_densify_stats", "gso_densify_select", "gso_mark_nonzero", "gso_prune_mask", "gso_split_children", "gso_compact_temp_bytes", "gso_compact_map",
-            "gso_gather_rows", "gsr_status_string")
+            "gso_gather_rows", "gsr_status_string", "gsr_struct_bytes")
 
 
 NUM_PROFILE_EVENTS = 21
 EVENT_NAMES = ("stage1_begin", "preprocess", "scan", "stage2_begin", "depth_order", "emit", "sort", "ranges", "render",
                "finish", "bwd_begin", "bwd_clear", "bwd_render", "bwd_preprocess", "batch_begin", "batch",
-               "fwd_batch_begin", "fwd_batch", "tile_count")
+               "fwd_batch_begin", "fwd_batch", "tile_count", "fwd_batch_sort_begin", "fwd_batch_sort")
 
 # Optional per-thread hook used by bench.py: a ctypes array of hipEvent_t handles
 # that the next rasterizer calls record around their kernels.

@@ -57,6 +57,17 @@ extern "C" {
 size_t gsr_geom_bytes(int P) { return geom_buf(nullptr, (size_t)(P > 0 ? P : 0)).bytes; }
 size_t gsr_image_bytes(int W, int H) { return image_view(nullptr, (size_t)W, (size_t)H).bytes; }
 size_t gsr_binning_bytes(int64_t R) { return bin_view(nullptr, (size_t)(R > 0 ? R : 0)).bytes; }
+size_t gsr_struct_bytes(int which) {
+    switch (which) {
+        case 0: return sizeof(GsrScene);
+        case 1: return sizeof(GsrForwardOut);
+        case 2: return sizeof(GsrBackwardIO);
+        case 3: return sizeof(GsrBackwardView);
+        case 4: return sizeof(GsrForwardView);
+        case 5: return sizeof(GsrLayout);
+        default: return 0;
+    }
+}
 size_t gsr_backward_work_bytes(int P) { return align_up((size_t)(P > 0 ? P : 1) * sizeof(GradRec), 256); }
 size_t gsr_sort_temp_error_offset(void) {
     char* const z = (char*)4096;

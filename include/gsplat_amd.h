@@ -305,6 +305,11 @@ typedef struct {
 } GsrLayout;
 int gsr_layout(int P, int W, int H, int64_t num_rendered, GsrLayout* out);
 
+/* sizeof of the structs above as the library was built, for bindings that mirror them field by field
+ * (ctypes, cgo, JNA): 0 GsrScene, 1 GsrForwardOut, 2 GsrBackwardIO, 3 GsrBackwardView, 4 GsrForwardView,
+ * 5 GsrLayout; 0 for any other number.  No counterpart in the reference, whose operator passes tensors. */
+size_t gsr_struct_bytes(int which);
+
 /* The sorted instance list as the reference holds it: point_list_keys[i] = (tile << 32 | depth bits)
  * (rasterizer_impl.cu:93-104, BinningState::point_list_keys).  This implementation sorts
  * (tile id, Gaussian index) pairs emitted in depth order and does not store the 64-bit keys; this

@@ -29,6 +29,18 @@ def test_library_exports_every_declared_symbol():
     assert sorted(EXPORTED) == names
 
 
+def test_binding_structs_match_the_library():
+    """The ctypes structures mirror include/gsplat_amd.h field by field; the library reports its own sizes
+    (the loader compares them too, so a stale library fails at import instead of corrupting a call)."""
+    import _gsplat_lib as G
+    L = G.lib()
+    for which, cls in enumerate((G.GsrScene, G.GsrForwardOut, G.GsrBackwardIO, G.GsrBackwardView, G.GsrForwardView,
+                                 G.GsrLayout)):
+        assert L.gsr_struct_bytes(which) == C.sizeof(cls) > 0, cls.__name__
+    assert L.gsr_struct_bytes(6) == 0 and L.gsr_struct_bytes(-1) == 0
+    assert len(G.EVENT_NAMES) == G.NUM_PROFILE_EVENTS
+
+
 def test_size_queries_and_layout():
     from _gsplat_lib import GsrLayout, lib
     L = lib()
