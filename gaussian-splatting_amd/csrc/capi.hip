@@ -74,6 +74,7 @@ size_t gsr_sort_temp_error_offset(void) {
     return (size_t)((char*)sort_temp_view(z, 1, 0).err - z);
 }
 void gsr_test_force_wide_sort_status(int on) { sort_set_force_wide(on != 0); }
+void gsr_test_forward_reach_masks(int mode) { render_fwd_set_reach_masks(mode); }
 void gsr_test_inject_sort_error(int on) { g_inject_sort_error.store(on ? 1 : 0, std::memory_order_relaxed); }
 size_t gsr_sort_temp_bytes(int64_t n) { return sort_temp_view(nullptr, (size_t)(n > 0 ? n : 1), SORT_MAX_PASSES).bytes; }
 
@@ -176,7 +177,7 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
         mark(s, GSR_EV_RANGES, st);
         point_list = b.vals[res];
     }
-    GSR_TRY(launch_render_fwd(*s, *o, g, im, point_list, st));
+    GSR_TRY(launch_render_fwd(*s, *o, g, im, point_list, R, o->num_visible, st));
     mark(s, GSR_EV_RENDER, st);
     // The sorts' look-back spins are bounded; a tripped limit sets an error word in the sort's temp area.
     // With debug the call waits and reports it; otherwise the last kernel stores the word to the caller's

@@ -135,6 +135,33 @@ __device__ __forceinline__ float wave_transpose_sum16(const float (&v)[16]) {
 // and / andn2 avoids the v_cndmask + v_cmp pair the compiler emits for a ballot of a
 // boolean expression.
 __device__ __forceinline__ uint64_t lanes_where(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// Which of the four 8x8 quadrants of the 16x16 tile at (x0, y0) can hold a pixel with
+// power >= tau for the splat at (x, y) with conic (a, b, c) — bit q for the quadrant at
+// (x0 + 8 (q & 1), y0 + 8 (q >> 1)) — from the bounding box of the ellipse
+// a dx^2 + 2 b dx dy + c dy^2 <= -2 tau, whose half extents are sqrt(-2 tau c / det) and
+// sqrt(-2 tau a / det).  Conservative: the box is enlarged by 0.1 % + 0.01 pixel, which is far more
+// than the rounding of the power as the blend kernels compute it can move the ellipse as long as
+// the conic is not nearly degenerate (b^2 < 0.99 a c: then a dx^2 + c dy^2 <= 200 times the
+// quadratic form, so a few ulps of its terms are < 1e-4 of its value); nearly degenerate or
+// indefinite conics get all four bits.  tau > 0 (alpha >= 1/255 out of reach): no bit.
+// A quadrant without its bit has, besides no pixel with power >= tau, no pixel with power > 0
+// either, also as computed (b^2 < 0.99 a c puts the power at least 0.5 % of its largest term
+// below zero; only at dx = dy = 0 it is 0): the forward blend's statistics rely on that.
+__device__ __forceinline__ uint32_t quadrant_reach_bits(float x, float y, float a, float b, float c, float tau,
+                                                        float x0, float y0) {
+    const float det = a * c - b * b;
+    if (!(a > 0.0f && c > 0.0f && det > 0.01f * a * c)) return 0xFu;
+    if (tau > 0.0f) return 0u;
+    const float s = -2.0f * tau * __builtin_amdgcn_rcpf(det);
+    const float hx = __builtin_amdgcn_sqrtf(s * c) * 1.001f + 0.01f;
+    const float hy = __builtin_amdgcn_sqrtf(s * a) * 1.001f + 0.01f;
+    // pixel centres of the quadrant columns: x0 .. x0 + 7 and x0 + 8 .. x0 + 15 (rows likewise)
+    const uint32_t cx = (x - hx <= x0 + 7.0f && x + hx >= x0 ? 1u : 0u) | (x - hx <= x0 + 15.0f && x + hx >= x0 + 8.0f ? 2u : 0u);
+    const uint32_t cy = (y - hy <= y0 + 7.0f && y + hy >= y0 ? 1u : 0u) | (y - hy <= y0 + 15.0f && y + hy >= y0 + 8.0f ? 2u : 0u);
+    // bit q = column bit (q & 1) and row bit (q >> 1)
+    return ((cy & 1u) ? cx : 0u) | ((cy & 2u) ? cx << 2 : 0u);
+}
 __device__ __forceinline__ bool lane_in(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 typedef float f2 __attribute__((ext_vector_type(2)));

@@ -66,6 +66,7 @@ struct __attribute__((aligned(16))) GradRec {
 static_assert(sizeof(GradRec) == 64, "GradRec must be 64 bytes");
 
 int sort_passes_for(int begin_bit, int end_bit);
+void render_fwd_set_reach_masks(int mode);   // test hook: 1 / 0 forces the forward blend with / without reach masks, -1 automatic
 void sort_set_force_wide(bool on);   // test hook: 64-bit look-back status words at any size
 
 hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, const GeomBuf& g, hipStream_t st);
@@ -129,7 +130,7 @@ hipError_t launch_radix_sort_u32(uint32_t* keys[2], uint32_t* vals[2], int64_t n
                                  void* temp, hipStream_t st, int* result_buffer, bool hist_ready);
 
 hipError_t launch_render_fwd(const GsrScene& s, const GsrForwardOut& o, const GeomBuf& g, const ImageView& im,
-                             const uint32_t* point_list, hipStream_t st);
+                             const uint32_t* point_list, int64_t num_rendered, int64_t num_visible, hipStream_t st);
 hipError_t launch_render_bwd(const GsrScene& s, const GeomBuf& g, const ImageView& im, const uint32_t* point_list,
                              const GsrBackwardIO& io, GradRec* acc, hipStream_t st);
 hipError_t launch_preprocess_bwd(const GsrScene& s, const int* radii, const GeomBuf& g, const GsrBackwardIO& io,

@@ -50,6 +50,9 @@ render_bwd_kernel(const RenderBwdArgs a) {
     float4* const s_q3 = s_q[3];  // rep0 .. rep3
     __shared__ float s_acc[BWD_BATCH][16];
     __shared__ uint32_t s_max[4];
+    // s_reach[q][h]: bit i = entry 64 h + i of the round can give a gradient in quadrant q: one of q's pixels
+    // still had it in its list, and its alpha >= 1/255 ellipse reaches the quadrant (quadrant_reach_bits)
+    __shared__ uint64_t s_reach[4][BWD_BATCH / 64];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = xcd_remap_b(blockIdx.x, a.ntiles);
@@ -109,8 +112,10 @@ render_bwd_kernel(const RenderBwdArgs a) {
     for (int base = 0; base < max_last; base += BWD_BATCH) {
         __syncthreads();
         const int nb = min(BWD_BATCH, max_last - base);
+        uint32_t reach = 0;
         if (tid < nb) {
-            const uint32_t id = a.point_list[range.x + (uint32_t)(max_last - 1 - base - tid)];
+            const uint32_t contributor = (uint32_t)(max_last - 1 - base - tid);
+            const uint32_t id = a.point_list[range.x + contributor];
             const float4* r4 = reinterpret_cast<const float4*>(a.rec + id);
             const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
             s_q0[tid] = make_float4(r0.x, r0.y, -0.5f * r0.z, -0.5f * r1.x);
@@ -122,6 +127,17 @@ render_bwd_kernel(const RenderBwdArgs a) {
                 const float4 r3 = r4[3];
                 s_q3[tid] = make_float4(r2.z, r2.w, r3.x, r3.y);
             }
+            reach = quadrant_reach_bits(r0.x, r0.y, r0.z, r0.w, r1.x, tau, (float)(tx * TILE_X), (float)(ty * TILE_Y));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (contributor >= s_max[q]) reach &= ~(1u << q);   // behind the last entry any pixel of q blended
+        }
+        if (w < BWD_BATCH / 64) {   // the staging waves: whole waves take part in the ballots
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t bq = lanes_where((reach >> q) & 1u);
+                if (lane == 0) s_reach[q][w] = bq;
+            }
         }
         {
             float4* z = reinterpret_cast<float4*>(&s_acc[0][0]) + tid;  // 128 x 16 floats = 512 float4
@@ -130,20 +146,28 @@ render_bwd_kernel(const RenderBwdArgs a) {
         __syncthreads();
 
         typedef __attribute__((address_space(3))) float4 lds_f4;
-        uint32_t qaddr = (uint32_t)(uintptr_t)(lds_f4*)&s_q[0][0];
-        asm volatile("" : "+v"(qaddr));
-#pragma unroll 1   // unrolling 2x / 4x changes nothing measurable
-        for (int j = 0; j < nb; ++j) {
+        const uint32_t qbase = (uint32_t)(uintptr_t)(lds_f4*)&s_q[0][0];
+        // The wave visits the entries that can give its quadrant a gradient, in list order (the others
+        // would leave every pixel's state as it is and add exact zeros).
+#pragma unroll 1
+        for (int half = 0; half < BWD_BATCH / 64; ++half) {
+          const uint64_t mine = s_reach[w][half];
+          uint64_t todo = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(mine >> 32)) << 32) |
+                          __builtin_amdgcn_readfirstlane((uint32_t)mine);
+#pragma unroll 1
+          while (todo) {
+            const int j = half * 64 + __builtin_ctzll(todo);
+            todo &= todo - 1;
             const uint32_t contributor = (uint32_t)(max_last - 1 - base - j);
-            // the LDS address of entry j lives in a VGPR that is advanced per visit; all four reads of a
-            // visit use it with immediate offsets (the compiler would copy it from an SGPR before each)
+            // the LDS address of entry j in a VGPR; all four reads of a visit use it with immediate offsets
+            // (the compiler would copy it from an SGPR before each)
+            uint32_t qa = qbase + 16u * (uint32_t)j;
+            asm volatile("" : "+v"(qa));
             float4 q0, q1;
             asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
                          : "=&v"(q0), "=&v"(q1)
-                         : "v"(qaddr), "i"((int)(BWD_BATCH * sizeof(float4)))
+                         : "v"(qa), "i"((int)(BWD_BATCH * sizeof(float4)))
                          : "memory");
-            const uint32_t qa = qaddr;
-            qaddr += 16;
             f2 d;
             const float power = splat_power_prescaled((f2){q0.x, q0.y}, pix, (f2){q0.z, q0.w}, q1.x, &d);
             const float dx = d.x, dy = d.y;
@@ -247,6 +271,7 @@ render_bwd_kernel(const RenderBwdArgs a) {
                                     g_r01.x, g_r01.y, g_r23.x, g_r23.y, 0.f, 0.f};
             const float tot = wave_transpose_sum16<14>(comp);
             if ((lane & 3) == 0) atomicAdd(&s_acc[j][acc_slot], tot);
+          }
         }
         __syncthreads();
         // 16 lanes per instance: one 64-byte GradRec update

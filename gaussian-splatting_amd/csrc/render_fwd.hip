@@ -10,6 +10,8 @@
 // reduced over the wave 16 instances at a time by a transposing reduction,
 // over the four waves through LDS, and leave the workgroup as one pair of
 // adjacent float atomics per instance.
+#include <atomic>
+
 #include "kernels.h"
 
 namespace gs {
@@ -37,7 +39,10 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-template <int DIM, bool INVD>
+// REACH: entries whose alpha >= 1/255 ellipse does not reach a wave's quadrant are not tested by that
+// wave (quadrant_reach_bits).  Pays when the splats are small against a tile; costs a scalar test and
+// two scalar copies per visit, which large splats (that reach every quadrant) do not earn back.
+template <int DIM, bool INVD, bool REACH>
 __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6, 6))) render_fwd_kernel(const RenderFwdArgs a) {
     // One SplatRec per instance, regrouped: the test of an instance needs the first two
     // quarters only, the other two feed packed (two-float) multiply-adds as they are.
@@ -49,6 +54,9 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
     __shared__ float s_gsum[4][TILE_PIX];
     __shared__ uint32_t s_gcnt[4][TILE_PIX];
     __shared__ int s_wdone[4];
+    // s_reach[q][g]: bit u = entry 16 g + u of the round reaches quadrant q (quadrant_reach_bits); without
+    // the bit no pixel of q can pass the alpha test and every pixel of q has a non-positive power
+    __shared__ uint32_t s_reach[4][TILE_PIX / 16];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = xcd_remap(blockIdx.x, a.ntiles);
@@ -74,6 +82,7 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
         __syncthreads();
         if (s_wdone[0] & s_wdone[1] & s_wdone[2] & s_wdone[3]) break;
         const int nb = min(TILE_PIX, total - base);
+        uint32_t reach = 0xFu;   // the padding entries below are visited (their power is positive everywhere)
         if (tid < nb) {
             const uint32_t id = a.point_list[range.x + base + tid];
             const float4* r4 = reinterpret_cast<const float4*>(a.rec + id);
@@ -90,10 +99,19 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
                 const float4 r3 = r4[3];
                 s_q3[tid] = make_float4(r2.z, r2.w, r3.x, r3.y);
             }
+            if (REACH)
+                reach = quadrant_reach_bits(r0.x, r0.y, r0.z, r0.w, r1.x, tau, (float)(tx * TILE_X), (float)(ty * TILE_Y));
         } else if (tid < ((nb + 15) & ~15)) {
             // the last group of 16 is filled up with entries whose power is positive everywhere
             s_q0[tid] = make_float4(-1e4f, -1e4f, 0.5f, 0.5f);
             s_q1[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (REACH) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {   // this wave staged the entries 64 w .. 64 w + 63: four groups of 16
+                const uint64_t bq = lanes_where((reach >> q) & 1u);
+                if (lane < 4) s_reach[q][4 * w + lane] = (uint32_t)(bq >> (16 * lane)) & 0xffffu;
+            }
         }
         __syncthreads();
 
@@ -119,23 +137,33 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
             uint64_t cnt_lo = 0, cnt_hi = 0;  // byte u: number of pixels of the wave that tested instance j0 + u
 #pragma unroll
             for (int u = 0; u < 16; ++u) tv[u] = 0.f;
+            const uint32_t reached = REACH ? __builtin_amdgcn_readfirstlane(s_reach[w][j0 >> 4]) : 0xffffu;
+            uint64_t none = 0;   // "no pixel can pass", opaque to the compiler (it would split the shared part again)
+            asm volatile("" : "+s"(none));
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int j = j0 + u;
+                // An entry out of this quadrant's reach is not read: every live pixel tests it (power <= 0),
+                // none can blend it.  Only the test is branched around; what follows is shared, so that
+                // the pixels' state does not meet itself at a join (the register allocator then copies it).
+                uint64_t hm = live, pm = none;
                 float4 q0, q1;
-                asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(q0), "=&v"(q1)
-                             : "v"(gbase), "i"(16 * u), "i"((int)(TILE_PIX * sizeof(float4)) + 16 * u)
-                             : "memory");
-                f2 d;
-                const float power = splat_power_prescaled((f2){q0.x, q0.y}, pix, (f2){q0.z, q0.w}, q1.x, &d);
-                // forward.cu:423-432: the statistics count every pixel that reaches this instance with a
-                // non-positive power, whatever its alpha
-                const uint64_t hm = lanes_where(!(power > 0.0f)) & live;
+                float power = 0.f;
+                if (!REACH || ((reached >> u) & 1u)) {
+                    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(q0), "=&v"(q1)
+                                 : "v"(gbase), "i"(16 * u), "i"((int)(TILE_PIX * sizeof(float4)) + 16 * u)
+                                 : "memory");
+                    f2 d;
+                    power = splat_power_prescaled((f2){q0.x, q0.y}, pix, (f2){q0.z, q0.w}, q1.x, &d);
+                    // forward.cu:423-432: the statistics count every pixel that reaches this instance with a
+                    // non-positive power, whatever its alpha
+                    hm = lanes_where(!(power > 0.0f)) & live;
+                    pm = lanes_where(power >= q1.y) & hm;
+                }
                 tv[u] = select_or_zero(hm, T);
                 if (u < 8) cnt_lo |= (uint64_t)__popcll(hm) << (8 * u);
                 else cnt_hi |= (uint64_t)__popcll(hm) << (8 * (u - 8));
-                const uint64_t pm = lanes_where(power >= q1.y) & hm;
                 if (pm == 0) continue;  // no pixel of the wave can pass the alpha test
 
                 // lanes outside pm compute values nobody reads
@@ -220,8 +248,11 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
     }
 }
 
+static std::atomic<int> g_reach_masks{-1};
+void render_fwd_set_reach_masks(int mode) { g_reach_masks.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
+
 hipError_t launch_render_fwd(const GsrScene& s, const GsrForwardOut& o, const GeomBuf& g, const ImageView& im,
-                             const uint32_t* point_list, hipStream_t st) {
+                             const uint32_t* point_list, int64_t num_rendered, int64_t num_visible, hipStream_t st) {
     RenderFwdArgs a;
     a.ranges = im.ranges;
     a.point_list = point_list;
@@ -241,13 +272,19 @@ hipError_t launch_render_fwd(const GsrScene& s, const GsrForwardOut& o, const Ge
     a.out_reps = o.out_reps;
     const dim3 grid(a.ntiles), block(TILE_PIX);
     const bool invd = o.out_invdepth != nullptr;
+    // small splats (fewer than six tiles per rendered Gaussian on average): the quadrant reach masks pay
+    const int64_t nvis = num_visible > 0 ? num_visible : s.P;
+    const int forced = g_reach_masks.load(std::memory_order_relaxed);
+    const bool reach = forced < 0 ? num_rendered < 6 * nvis : forced != 0;
+#define GS_LAUNCH_FWD(D, I, R) hipLaunchKernelGGL((render_fwd_kernel<D, I, R>), grid, block, 0, st, a)
     if (s.DIM == 4) {
-        if (invd) hipLaunchKernelGGL((render_fwd_kernel<4, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((render_fwd_kernel<4, false>), grid, block, 0, st, a);
+        if (invd) { if (reach) GS_LAUNCH_FWD(4, true, true); else GS_LAUNCH_FWD(4, true, false); }
+        else { if (reach) GS_LAUNCH_FWD(4, false, true); else GS_LAUNCH_FWD(4, false, false); }
     } else {
-        if (invd) hipLaunchKernelGGL((render_fwd_kernel<0, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((render_fwd_kernel<0, false>), grid, block, 0, st, a);
+        if (invd) { if (reach) GS_LAUNCH_FWD(0, true, true); else GS_LAUNCH_FWD(0, true, false); }
+        else { if (reach) GS_LAUNCH_FWD(0, false, true); else GS_LAUNCH_FWD(0, false, false); }
     }
+#undef GS_LAUNCH_FWD
     return hipGetLastError();
 }
 

@@ -423,6 +423,11 @@ int gso_gather_rows(const void* src, void* dst, const uint32_t* src_of_dst, int6
  * at any size (gsr_sort_temp_bytes and gsr_binning_bytes answer accordingly). */
 void gsr_test_force_wide_sort_status(int on);
 
+/* Test hook: which forward blend kernel gsr_forward_stage2 takes.  The kernel that leaves out, per 8x8 pixel
+ * quadrant, the list entries whose alpha >= 1/255 ellipse cannot reach the quadrant is chosen when a view's
+ * splats cover fewer than six tiles on average; 1 always takes it, 0 never, -1 restores the choice. */
+void gsr_test_forward_reach_masks(int mode);
+
 /* Test hook: while on, every gsr_forward_stage2 sets its sort's error word as a tripped look-back would. */
 void gsr_test_inject_sort_error(int on);
 

@@ -80,8 +80,17 @@ def _check_forward(oracle, sc, aa, bg, **variant):
 
 
 @pytest.mark.parametrize("name,make,aa,bg", _scenes(), ids=[s[0] for s in _scenes()])
-def test_forward_parity(oracle, name, make, aa, bg):
-    _check_forward(oracle, make(), aa, bg)
+@pytest.mark.parametrize("reach", [-1, 0, 1], ids=["auto", "plain_kernel", "reach_masks"])
+def test_forward_parity(oracle, name, make, aa, bg, reach):
+    """reach: both forward blend kernels on every scene (the one that leaves out, per quadrant, the list entries
+    that cannot reach it is otherwise only chosen for views of small splats); integer outputs, hit counts
+    included, are bit-exact with either."""
+    from _gsplat_lib import lib
+    try:
+        lib().gsr_test_forward_reach_masks(reach)
+        _check_forward(oracle, make(), aa, bg)
+    finally:
+        lib().gsr_test_forward_reach_masks(-1)
 
 
 def test_forward_parity_precomputed_and_no_reps(oracle):
