@@ -154,7 +154,7 @@ class KernelTimer:
 
 
 def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1, walked=None, from_rects=True, reached=None,
-                      reached_any=None):
+                      reached_any=None, packed=False):
     """Bytes one launch must move at least: per-unit figures times the units one
     launch processes.  Preprocess and blend figures of the one-view kernels are
     those of the reference data layout; the binning stages and the two batch
@@ -171,12 +171,16 @@ def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1, walked=None, from_
         "preprocess": 315.0 * visible + 20.0 * (P - visible),
         "depth_order": P * (16.0 + 8.0 + 4.0 + 4 * 16.0),       # bin read, pair write, histogram read, 4 passes
         "depth_order_batch": V * P * (16.0 + 8.0 + 4.0 + 4 * 16.0),   # the same for the V views of a step in shared launches
-        "emit_keys": P * (4.0 + 16.0 + 16.0 + 16.0) + 8.0 * R,  # gather + sbin write + sbin read, pair write
+        # gather + sbin write + sbin read; an instance leaves as one word (low tile digit | Gaussian index)
+        # when the indices fit below the digit, else as a (tile id, index) pair
+        "emit_keys": P * (4.0 + 16.0 + 16.0 + 16.0) + (4.0 if packed else 8.0) * R,
         # the digit histograms and the tile ranges come from the tile rectangles (16 B per Gaussian) when the
         # tile grid fits one workgroup's LDS; otherwise from a histogram sweep and a range scan over the keys
         "tile_count": P * 16.0 if from_rects else None,
         # two-digit tile ids with rectangle counts: the emission partitions by the high digit, one pass is left
-        "sort": R * ((0.0 if from_rects else 4.0) + (1 if from_rects and passes == 2 else passes) * 16.0),
+        # (packed instances: one word read, the Gaussian index written)
+        "sort": R * ((0.0 if from_rects else 4.0) + (1 if from_rects and passes == 2 else passes) *
+                     (8.0 if packed else 16.0)),
         "tile_ranges": None if from_rects else 4.0 * R,
         "render_fwd": 28.0 * walked + 48.0 * HW,
         "render_bwd": 60.0 * walked + 40.0 * HW + 56.0 * walked,
@@ -596,6 +600,9 @@ def main():
     gx, gy = (W + 15) // 16, (H + 15) // 16
     passes = ((gx * gy).bit_length() + 7) // 8   # the instance sort only orders the tile bits
     from_rects = ((gx + 1) * (gy + 1) + passes * 256 + 17) * 4 <= 150 * 1024   # as tile_counts_fit in the library
+    tile_bits = (gx * gy).bit_length()
+    low_digit_bits = tile_bits // 2 + tile_bits % 2
+    packed = from_rects and passes == 2 and P <= (1 << (32 - low_digit_bits))   # as fused_sort_packs in the library
 
     # workload counters of this rank's views (outside the timed region)
     vis_l, R_l, pairs_l, reached_l = [], [], [], []
@@ -767,7 +774,8 @@ def main():
         launches = lambda k: 1 if k in KernelTimer.PER_STEP else V          # per step
 
         def alg(k):
-            return algorithmic_bytes(k, P, visible, R, H * W, passes, V, walked, from_rects, reached, reached_any)
+            return algorithmic_bytes(k, P, visible, R, H * W, passes, V, walked, from_rects, reached, reached_any,
+                                     packed)
 
         for k, ms in kernels.items():
             ab = alg(k)
@@ -840,7 +848,8 @@ def main():
             # lower bound for the sort alone).  `sort_u64` (extras) is the stand-alone 64-bit sort of the C ABI.
             "sort_GBps": (R * 12.0 / ((kernels["sort"] + kernels["depth_order"] + kernels.get("depth_order_batch", 0.0) / V +
                                        kernels["emit_keys"]) * 1e-3) / 1e9) if R else None,
-            "sort_hbm_GBps": (algorithmic_bytes("sort", P, visible, R, H * W, passes, V, walked, from_rects) /
+            "sort_hbm_GBps": (algorithmic_bytes("sort", P, visible, R, H * W, passes, V, walked, from_rects,
+                                                packed=packed) /
                               (kernels["sort"] * 1e-3) / 1e9) if R else None,
         }
         if overlapping:

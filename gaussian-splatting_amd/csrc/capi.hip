@@ -10,6 +10,7 @@ using namespace gs;
 namespace {
 
 std::atomic<int> g_inject_sort_error{0};  // test hook only (gsr_test_inject_sort_error)
+std::atomic<int> g_packed_sort{1};        // test hook only (gsr_test_packed_instances)
 
 inline int hip_status(hipError_t e) { return e == hipSuccess ? GSR_OK : GSR_ERR_HIP; }
 
@@ -76,6 +77,7 @@ size_t gsr_sort_temp_error_offset(void) {
 void gsr_test_force_wide_sort_status(int on) { sort_set_force_wide(on != 0); }
 void gsr_test_forward_reach_masks(int mode) { render_fwd_set_reach_masks(mode); }
 void gsr_test_inject_sort_error(int on) { g_inject_sort_error.store(on ? 1 : 0, std::memory_order_relaxed); }
+void gsr_test_packed_instances(int on) { g_packed_sort.store(on ? 1 : 0, std::memory_order_relaxed); }
 size_t gsr_sort_temp_bytes(int64_t n) { return sort_temp_view(nullptr, (size_t)(n > 0 ? n : 1), SORT_MAX_PASSES).bytes; }
 
 int gsr_forward_stage1(const GsrScene* s, GsrForwardOut* o, void* stream, int64_t* num_rendered) {
@@ -140,6 +142,9 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
         const int n = (o->num_visible > 0 && o->num_visible <= s->P) ? (int)o->num_visible : s->P;
         // two-digit tile ids: the emission partitions by the high digit, one segmented pass does the low one
         const bool fused = from_rects && fused_sort_fits(R, n, nbits);
+        // ... and when every Gaussian index fits beside the low digit in 32 bits, an instance is one word
+        // between the two kernels instead of a (tile id, index) pair
+        const bool packed = fused && fused_sort_packs(s->P, nbits) && g_packed_sort.load(std::memory_order_relaxed);
         if (fused) {
             uint32_t *ghist, *seg_start, *seg_tile0;
             int lowshift, lowbits;
@@ -161,9 +166,9 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
             mark(s, GSR_EV_DEPTH_ORDER, st);
             if (fused) {
                 GSR_TRY(launch_order_gather(g, g.dvals[ord], n, st));
-                GSR_TRY(launch_emit_partition(g, n, (s->W + TILE_X - 1) / TILE_X, nbits, R, b.keys, b.vals, b.sort_temp, st));
+                GSR_TRY(launch_emit_partition(g, n, (s->W + TILE_X - 1) / TILE_X, nbits, R, b.keys, b.vals, b.sort_temp, st, packed));
                 mark(s, GSR_EV_EMIT, st);
-                GSR_TRY(launch_segmented_pass(n, ntiles, nbits, R, im.ranges, b.keys, b.vals, b.sort_temp, st));
+                GSR_TRY(launch_segmented_pass(n, ntiles, nbits, R, im.ranges, b.keys, b.vals, b.sort_temp, st, packed));
                 res = 0;
             } else {
                 GSR_TRY(launch_emit_keys(*s, g, g.dvals[ord], n, b.keys[0], b.vals[0], st));
@@ -423,14 +428,16 @@ int gsr_layout(int P, int W, int H, int64_t R, GsrLayout* out) {
 }
 
 int gsr_sorted_keys_u64(int P, int W, int H, int64_t R, const void* geom_buffer, const void* binning_buffer,
-                        uint64_t* keys_out, void* stream) {
+                        const void* image_buffer, uint64_t* keys_out, void* stream) {
     if (P < 0 || W <= 0 || H <= 0 || R < 0) return GSR_ERR_ARG;
     if (R == 0) return GSR_OK;
-    if (!geom_buffer || !binning_buffer || !keys_out) return GSR_ERR_ARG;
+    if (!geom_buffer || !binning_buffer || !image_buffer || !keys_out) return GSR_ERR_ARG;
     const GeomBuf g = geom_buf(geom_buffer, (size_t)P);
     const BinView b = bin_view((void*)binning_buffer, (size_t)R);
+    const ImageView im = image_view((void*)image_buffer, (size_t)W, (size_t)H);
+    const int ntiles = ((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
     const int res = sort_passes_for(0, tile_bits(W, H)) & 1;
-    return hip_status(launch_keys64(g, b.keys[res], b.vals[res], R, keys_out, (hipStream_t)stream));
+    return hip_status(launch_keys64(g, im.ranges, ntiles, b.vals[res], R, keys_out, (hipStream_t)stream));
 }
 
 size_t gsk_dist2_temp_bytes(int P) { return knn_temp_bytes(P); }

@@ -711,13 +711,15 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* keys, 
     if (i == R - 1) ranges[cur].y = (uint32_t)R;
 }
 
-// The reference's 64-bit sort keys, rebuilt from the sorted tile ids and the
-// depth of each instance's Gaussian (for inspection and tests).
-__global__ void __launch_bounds__(256) keys64_kernel(const uint32_t* tile_keys, const uint32_t* point_list,
+// The reference's 64-bit sort keys, rebuilt from the tile ranges (the tile an instance of the sorted
+// list belongs to) and the depth of each instance's Gaussian (for inspection and tests).  One workgroup
+// per tile walks that tile's part of the list.
+__global__ void __launch_bounds__(256) keys64_kernel(const uint2* ranges, const uint32_t* point_list,
                                                      const uint2* dt, int64_t R, uint64_t* out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= R) return;
-    out[i] = ((uint64_t)tile_keys[i] << 32) | dt[point_list[i]].x;
+    const uint32_t tile = blockIdx.x;
+    const uint2 r = ranges[tile];
+    for (int64_t i = (int64_t)r.x + threadIdx.x; i < (int64_t)r.y && i < R; i += 256)
+        out[i] = ((uint64_t)tile << 32) | dt[point_list[i]].x;
 }
 
 // Also the last kernel of a forward pass: it hands the sort's error word to the caller's host word
@@ -860,11 +862,10 @@ hipError_t launch_tile_ranges(const uint32_t* keys, int64_t R, uint2* ranges, in
     return hipGetLastError();
 }
 
-hipError_t launch_keys64(const GeomBuf& g, const uint32_t* tile_keys, const uint32_t* point_list, int64_t R,
+hipError_t launch_keys64(const GeomBuf& g, const uint2* ranges, int ntiles, const uint32_t* point_list, int64_t R,
                          uint64_t* out, hipStream_t st) {
-    if (R <= 0) return hipSuccess;
-    hipLaunchKernelGGL(keys64_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, tile_keys, point_list, g.dt,
-                       R, out);
+    if (R <= 0 || ntiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(keys64_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, ranges, point_list, g.dt, R, out);
     return hipGetLastError();
 }
 

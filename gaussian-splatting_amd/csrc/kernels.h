@@ -86,7 +86,7 @@ hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, const uint32_t*
                             uint32_t* vals, hipStream_t st);
 hipError_t launch_tile_ranges(const uint32_t* keys, int64_t R, uint2* ranges, int ntiles, hipStream_t st);
 // (tile << 32 | depth bits) of every sorted instance, as the reference's sort keys.
-hipError_t launch_keys64(const GeomBuf& g, const uint32_t* tile_keys, const uint32_t* point_list, int64_t R,
+hipError_t launch_keys64(const GeomBuf& g, const uint2* ranges, int ntiles, const uint32_t* point_list, int64_t R,
                          uint64_t* out, hipStream_t st);
 // Unpacks the statistics; as the last kernel of the forward it also stores *sort_err (0 if null) to
 // *sort_err_host (device-accessible host memory, may be null).
@@ -119,10 +119,14 @@ hipError_t launch_order_gather(const GeomBuf& g, const uint32_t* order, int n, h
 bool fused_sort_fits(int64_t R, int n_visible, int nbits);
 hipError_t fused_sort_prepare(void* temp, int64_t R, int n_visible, int nbits, hipStream_t st, uint32_t** ghist,
                               uint32_t** seg_start, uint32_t** seg_tile0);
+// packed (fused_sort_packs: every Gaussian index fits below the low digit in 32 bits): between the two
+// kernels an instance is ONE word, (low digit << (32 - digit bits)) | Gaussian index, in keys[1]; the
+// segmented pass writes the Gaussian indices to vals[0] and nothing else (vals[1] and keys[0] stay unused).
+bool fused_sort_packs(int P, int nbits);
 hipError_t launch_emit_partition(const GeomBuf& g, int n_visible, int grid_x, int nbits, int64_t R, uint32_t* keys[2],
-                                 uint32_t* vals[2], void* temp, hipStream_t st);
+                                 uint32_t* vals[2], void* temp, hipStream_t st, bool packed);
 hipError_t launch_segmented_pass(int n_visible, int ntiles, int nbits, int64_t R, const uint2* ranges, uint32_t* keys[2],
-                                 uint32_t* vals[2], void* temp, hipStream_t st);
+                                 uint32_t* vals[2], void* temp, hipStream_t st, bool packed);
 // The same with 32-bit keys.  hist_ready: the digit histograms in the temp area were filled by the caller.
 hipError_t launch_radix_sort_u32_batch(int count, uint32_t* const (*keys)[2], uint32_t* const (*vals)[2], const int64_t* n,
                                        void* const* temp, hipStream_t st);

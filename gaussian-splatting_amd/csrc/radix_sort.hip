@@ -175,7 +175,7 @@ struct SegArgs {
     int nseg, ntiles;
 };
 
-template <class K, int THREADS, int ITEMS, int BITS, bool SEG, class S = uint32_t>
+template <class K, int THREADS, int ITEMS, int BITS, bool SEG, class S = uint32_t, bool PACKED = false>
 __device__ __forceinline__ void onesweep_tile(const K* __restrict__ kin, const uint32_t* __restrict__ vin,
                                               K* __restrict__ kout, uint32_t* __restrict__ vout, int64_t n, int shift,
                                               int bits, const uint32_t* __restrict__ gbase, S* status, uint32_t* ticket,
@@ -224,7 +224,7 @@ __device__ __forceinline__ void onesweep_tile(const K* __restrict__ kin, const u
         const int64_t i = wave_base + k * 64 + lane;
         const bool ok = i < n;
         key[k] = ok ? kin[i] : (K)~(K)0;
-        val[k] = ok ? vin[i] : 0u;
+        val[k] = (ok && !PACKED) ? vin[i] : 0u;
     }
 
     // 1. Tile histogram, published at once so that later tiles can look back
@@ -342,7 +342,7 @@ __device__ __forceinline__ void onesweep_tile(const K* __restrict__ kin, const u
         rank[k] = s_dstart[d] + s_whist[w * 256 + d] + rank[k];  // slot inside the tile
         if (ok) {
             s_keys[rank[k]] = key[k];
-            if (ONE_PHASE) s_vals[rank[k]] = val[k];
+            if (ONE_PHASE && !PACKED) s_vals[rank[k]] = val[k];
         }
     }
     __syncthreads();
@@ -357,8 +357,12 @@ __device__ __forceinline__ void onesweep_tile(const K* __restrict__ kin, const u
             const K kk = s_keys[pos];
             const uint32_t d = (uint32_t)(kk >> shift) & dmask;
             dst[k] = s_gofs[d] + pos;
-            kout[dst[k]] = kk;
-            if (ONE_PHASE) vout[dst[k]] = s_vals[pos];
+            if (PACKED) {
+                vout[dst[k]] = (uint32_t)kk & ((1u << shift) - 1u);  // the value sits below the digit
+            } else {
+                kout[dst[k]] = kk;
+                if (ONE_PHASE) vout[dst[k]] = s_vals[pos];
+            }
         }
     }
     if (ONE_PHASE) return;
@@ -377,12 +381,13 @@ __device__ __forceinline__ void onesweep_tile(const K* __restrict__ kin, const u
     }
 }
 
-template <class K, int THREADS, int ITEMS, int BITS, bool SEG, class S = uint32_t>
+template <class K, int THREADS, int ITEMS, int BITS, bool SEG, class S = uint32_t, bool PACKED = false>
 __global__ void __launch_bounds__(THREADS, (GS_OS_BLOCKS * THREADS) / 256)
 onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __restrict__ kout,
                 uint32_t* __restrict__ vout, int64_t n, int shift, int bits, const uint32_t* __restrict__ gbase,
                 S* status, uint32_t* ticket, uint32_t* err, const SegArgs seg) {
-    onesweep_tile<K, THREADS, ITEMS, BITS, SEG, S>(kin, vin, kout, vout, n, shift, bits, gbase, status, ticket, err, seg);
+    static_assert(!PACKED || (SEG && sizeof(K) == 4), "packed pairs only exist between the emission and the segmented pass");
+    onesweep_tile<K, THREADS, ITEMS, BITS, SEG, S, PACKED>(kin, vin, kout, vout, n, shift, bits, gbase, status, ticket, err, seg);
 }
 
 // One pass of several independent sorts (see SortBatchArgs).  Exactly ceil(n / tile) workgroups of a sort
@@ -451,6 +456,7 @@ struct EmitPartArgs {
     const uint32_t* offs;         // [nb256 + 1] exclusive instance offsets per block of 256 of them
     const uint2* chunk_first;     // [chunks + 1] block in which the chunk's first instance falls, that block's offset
     int n, nb256, grid_x, lowbits;
+    int vbits;                    // packed output: (low digit << vbits) | Gaussian index in kout, vout unused
     uint32_t R;
     const uint32_t* seg_start;    // [nseg + 1]
     uint32_t* status;             // [chunks][nseg]
@@ -470,7 +476,7 @@ __global__ void __launch_bounds__(256) chunk_map_kernel(int nb256, const uint32_
     if (b == nb256 - 1) chunk_first[chunks] = make_uint2((uint32_t)b, s0);  // "the chunk after the last" starts in the last block
 }
 
-template <int HB>
+template <int HB, bool PACKED>
 __global__ void __launch_bounds__(EP_THREADS) emit_partition_kernel(const EmitPartArgs a) {
     constexpr int NB = 1 << HB;  // segments = values of the high digit
     constexpr int NW = EP_THREADS / 64;
@@ -665,8 +671,12 @@ __global__ void __launch_bounds__(EP_THREADS) emit_partition_kernel(const EmitPa
         if (pos < chunk_n) {
             const uint32_t kk = s_keys[pos];
             const uint32_t dst = s_gofs[(kk >> a.lowbits) & hmask] + pos;
-            a.kout[dst] = kk;
-            a.vout[dst] = s_vals[pos];
+            if (PACKED) {
+                a.kout[dst] = ((kk & ((1u << a.lowbits) - 1u)) << a.vbits) | s_vals[pos];
+            } else {
+                a.kout[dst] = kk;
+                a.vout[dst] = s_vals[pos];
+            }
         }
     }
 }
@@ -834,8 +844,14 @@ hipError_t fused_sort_prepare(void* temp, int64_t R, int n_visible, int nbits, h
     return hipMemsetAsync(f.ghist, 0, f.zero_bytes, st);
 }
 
+bool fused_sort_packs(int P, int nbits) {
+    int lowshift, lowbits;
+    digit_of_pass(nbits, 2, 0, &lowshift, &lowbits);
+    return (int64_t)P <= ((int64_t)1 << (32 - lowbits));
+}
+
 hipError_t launch_emit_partition(const GeomBuf& g, int n_visible, int grid_x, int nbits, int64_t R, uint32_t* keys[2],
-                                 uint32_t* vals[2], void* temp, hipStream_t st) {
+                                 uint32_t* vals[2], void* temp, hipStream_t st, bool packed) {
     const FusedTemp f = fused_temp_view(temp, R, n_visible, nbits);
     int lowshift, lowbits;
     digit_of_pass(nbits, 2, 0, &lowshift, &lowbits);
@@ -855,6 +871,7 @@ hipError_t launch_emit_partition(const GeomBuf& g, int n_visible, int grid_x, in
     a.nb256 = nb256;
     a.grid_x = grid_x;
     a.lowbits = lowbits;
+    a.vbits = 32 - lowbits;
     a.R = (uint32_t)R;
     a.seg_start = f.seg_start;
     a.status = f.status_a;
@@ -863,22 +880,22 @@ hipError_t launch_emit_partition(const GeomBuf& g, int n_visible, int grid_x, in
     a.kout = keys[1];
     a.vout = vals[1];
     const dim3 grid(chunks), block(EP_THREADS);
-    switch (hb) {
-        case 1: hipLaunchKernelGGL(emit_partition_kernel<1>, grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL(emit_partition_kernel<2>, grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL(emit_partition_kernel<3>, grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL(emit_partition_kernel<4>, grid, block, 0, st, a); break;
-        case 5: hipLaunchKernelGGL(emit_partition_kernel<5>, grid, block, 0, st, a); break;
-        case 6: hipLaunchKernelGGL(emit_partition_kernel<6>, grid, block, 0, st, a); break;
-        case 7: hipLaunchKernelGGL(emit_partition_kernel<7>, grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL(emit_partition_kernel<8>, grid, block, 0, st, a); break;
+#define GS_EMIT_CASE(HB_)                                                                              \
+    case HB_:                                                                                          \
+        if (packed) hipLaunchKernelGGL((emit_partition_kernel<HB_, true>), grid, block, 0, st, a);     \
+        else hipLaunchKernelGGL((emit_partition_kernel<HB_, false>), grid, block, 0, st, a);           \
+        break;
+    switch (hb < 8 ? hb : 8) {
+        GS_EMIT_CASE(1) GS_EMIT_CASE(2) GS_EMIT_CASE(3) GS_EMIT_CASE(4)
+        GS_EMIT_CASE(5) GS_EMIT_CASE(6) GS_EMIT_CASE(7) GS_EMIT_CASE(8)
     }
+#undef GS_EMIT_CASE
     return hipGetLastError();
 }
 
 // The low digit inside each segment: keys[1] -> keys[0].
 hipError_t launch_segmented_pass(int n_visible, int ntiles, int nbits, int64_t R, const uint2* ranges, uint32_t* keys[2],
-                                 uint32_t* vals[2], void* temp, hipStream_t st) {
+                                 uint32_t* vals[2], void* temp, hipStream_t st, bool packed) {
     const FusedTemp f = fused_temp_view(temp, R, n_visible, nbits);
     int lowshift, lowbits;
     digit_of_pass(nbits, 2, 0, &lowshift, &lowbits);
@@ -892,12 +909,18 @@ hipError_t launch_segmented_pass(int n_visible, int ntiles, int nbits, int64_t R
     auto kern = onesweep_kernel<uint32_t, OS_THREADS, OS_ITEMS, 8, true>;
     if (lowbits <= 6) kern = onesweep_kernel<uint32_t, OS_THREADS, OS_ITEMS, 6, true>;
     else if (lowbits == 7) kern = onesweep_kernel<uint32_t, OS_THREADS, OS_ITEMS, 7, true>;
+    if (packed) {
+        kern = onesweep_kernel<uint32_t, OS_THREADS, OS_ITEMS, 8, true, uint32_t, true>;
+        if (lowbits <= 6) kern = onesweep_kernel<uint32_t, OS_THREADS, OS_ITEMS, 6, true, uint32_t, true>;
+        else if (lowbits == 7) kern = onesweep_kernel<uint32_t, OS_THREADS, OS_ITEMS, 7, true, uint32_t, true>;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)OS_LDS);
     if (e != hipSuccess) return e;
     const unsigned tiles = (unsigned)(R / SORT_TILE + seg.nseg + 1);  // an upper bound; the kernel knows the number
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(OS_THREADS), OS_LDS, st, (const uint32_t*)keys[1],
-                       (const uint32_t*)vals[1], keys[0], vals[0], R, 0, lowbits, (const uint32_t*)nullptr, f.status_b,
+                       (const uint32_t*)vals[1], keys[0], vals[0], R, packed ? 32 - lowbits : 0, lowbits,
+                       (const uint32_t*)nullptr, f.status_b,
                        f.ticket + 1, f.err, seg);
     return hipGetLastError();
 }

@@ -301,7 +301,10 @@ typedef struct {
     size_t rec, cov3D, tiles, clamped, block_sums, total;           /* geometry buffer */
     size_t final_T, n_contrib, ranges;                               /* image buffer */
     size_t keys0, keys1, vals0, vals1;                               /* binning buffer: u32 tile ids, u32 indices */
-    int sorted_buffer;                                               /* which keys/vals pair is sorted */
+    int sorted_buffer;                                               /* which pair holds the sorted list; its vals
+                                                                        array always does, its keys array (the sorted
+                                                                        tile ids) only when the instances were sorted
+                                                                        as pairs: see gsr_test_packed_instances */
 } GsrLayout;
 int gsr_layout(int P, int W, int H, int64_t num_rendered, GsrLayout* out);
 
@@ -313,9 +316,11 @@ size_t gsr_struct_bytes(int which);
 /* The sorted instance list as the reference holds it: point_list_keys[i] = (tile << 32 | depth bits)
  * (rasterizer_impl.cu:93-104, BinningState::point_list_keys).  This implementation sorts
  * (tile id, Gaussian index) pairs emitted in depth order and does not store the 64-bit keys; this
- * call rebuilds them on the device from the buffers a forward pass left (keys_out: device, R x u64). */
+ * call rebuilds them on the device from the buffers a forward pass left: the tile of an instance is
+ * the one whose range (image buffer) holds it, the depth bits are those of its Gaussian (geometry
+ * buffer), the Gaussian is the sorted list's entry (binning buffer).  keys_out: device, R x u64. */
 int gsr_sorted_keys_u64(int P, int W, int H, int64_t num_rendered, const void* geom_buffer,
-                        const void* binning_buffer, uint64_t* keys_out, void* stream);
+                        const void* binning_buffer, const void* image_buffer, uint64_t* keys_out, void* stream);
 
 /* simple-knn: mean squared distance to the 3 nearest neighbours. */
 size_t gsk_dist2_temp_bytes(int P);
@@ -427,6 +432,12 @@ void gsr_test_force_wide_sort_status(int on);
  * quadrant, the list entries whose alpha >= 1/255 ellipse cannot reach the quadrant is chosen when a view's
  * splats cover fewer than six tiles on average; 1 always takes it, 0 never, -1 restores the choice. */
 void gsr_test_forward_reach_masks(int mode);
+
+/* Test hook: how an instance travels between the key emission and the pass that orders each segment of
+ * tiles.  On (the default): as one 32-bit word, (low tile digit << (32 - digit bits)) | Gaussian index,
+ * whenever the tile ids have two digits and the number of Gaussians fits below the digit (2^25 Gaussians
+ * at 1080p, 2^24 at 4K); the sorted tile ids are then not stored.  Off: always as a (tile id, index) pair. */
+void gsr_test_packed_instances(int on);
 
 /* Test hook: while on, every gsr_forward_stage2 sets its sort's error word as a tripped look-back would. */
 void gsr_test_inject_sort_error(int on);

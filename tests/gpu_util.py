@@ -36,8 +36,9 @@ def run_forward_raw(rs, ten, colors_precomp=None, cov3D_precomp=None, with_reps=
     return dict(zip(names, out))
 
 
-def read_internals(out, P, W, H):
-    """Views into the scratch buffers (numpy copies)."""
+def read_internals(out, P, W, H, packed_pairs=None):
+    """Views into the scratch buffers (numpy copies).  packed_pairs=False: the forward ran with
+    gsr_test_packed_instances(0), so the sorted tile ids are in the binning buffer and are compared too."""
     from _gsplat_lib import GsrLayout, lib
     R = out["num_rendered"]
     lay = GsrLayout()
@@ -55,18 +56,19 @@ def read_internals(out, P, W, H):
     res["n_contrib"] = img[lay.n_contrib:lay.n_contrib + W * H * 4].view(np.uint32)
     res["ranges"] = img[lay.ranges:lay.ranges + ntiles * 8].view(np.uint32).reshape(ntiles, 2)
     if R > 0:
-        k = (lay.keys0, lay.keys1)[lay.sorted_buffer]
         v = (lay.vals0, lay.vals1)[lay.sorted_buffer]
-        res["tile_keys"] = binning[k:k + R * 4].view(np.uint32)
         res["point_list"] = binning[v:v + R * 4].view(np.uint32)
         # the reference's 64-bit keys (tile << 32 | depth bits), rebuilt by the library
         import torch
         keys = torch.empty(R, dtype=torch.int64, device=out["geom"].device)
         assert lib().gsr_sorted_keys_u64(P, W, H, R, out["geom"].data_ptr(), out["binning"].data_ptr(),
-                                         keys.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+                                         out["img"].data_ptr(), keys.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream) == 0
         torch.cuda.synchronize()
         res["keys"] = keys.cpu().numpy().view(np.uint64)
-        assert np.array_equal((res["keys"] >> np.uint64(32)).astype(np.uint32), res["tile_keys"])
+        if packed_pairs is False:   # the sorted tile ids are stored when the instances were sorted as pairs
+            k = (lay.keys0, lay.keys1)[lay.sorted_buffer]
+            assert np.array_equal((res["keys"] >> np.uint64(32)).astype(np.uint32), binning[k:k + R * 4].view(np.uint32))
     else:
         res["keys"] = np.zeros(0, np.uint64)
         res["point_list"] = np.zeros(0, np.uint32)

@@ -43,7 +43,7 @@ def _check_forward(oracle, sc, aa, bg, **variant):
     f = oracle.forward_from_scene(sc, bg=bg, antialiasing=aa, with_reps=with_reps, **kw_o)
     out = run_forward_raw(rs, ten, with_reps=with_reps, **kw_g)
     torch.cuda.synchronize()
-    it = read_internals(out, P, W, H)
+    it = read_internals(out, P, W, H, packed_pairs=variant.get("packed_pairs"))
     vis = f.radii > 0
     # bit-exact integers
     assert out["num_rendered"] == f.R
@@ -77,6 +77,20 @@ def _check_forward(oracle, sc, aa, bg, **variant):
         assert out["out_reps"].shape[0] == 0
     assert rel_err(out["gauss_sum"].cpu().numpy(), f.gauss_sum) <= REL_TOL
     return f, out, rs, ten, kw_g
+
+
+@pytest.mark.parametrize("name,make,aa,bg", _scenes(), ids=[s[0] for s in _scenes()])
+def test_forward_parity_with_instances_sorted_as_pairs(oracle, name, make, aa, bg):
+    """Between the key emission and the pass that orders each segment of tiles an instance normally travels
+    as one word (low tile digit above the Gaussian index); models with more Gaussians than fit below the
+    digit take (tile id, index) pairs.  That path forced on every scene: the same lists and ranges, and the
+    sorted tile ids it stores equal the tile part of the rebuilt keys."""
+    from _gsplat_lib import lib
+    try:
+        lib().gsr_test_packed_instances(0)
+        _check_forward(oracle, make(), aa, bg, packed_pairs=False)
+    finally:
+        lib().gsr_test_packed_instances(1)
 
 
 @pytest.mark.parametrize("name,make,aa,bg", _scenes(), ids=[s[0] for s in _scenes()])
