@@ -277,7 +277,7 @@ def roofline_entry(dom, ent, achieved_hbm, ab, traffic, ms):
         # wave_insts_per_launch between builds)
         return {"kernel": dom, "bound": "valu", "achieved": v["achieved_Ginst_s"], "peak": v["peak_Ginst_s"],
                 "unit": "G wave64-instructions/s", "frac": v["frac"], "traffic": traffic,
-                "wave_insts_per_launch": v["wave_insts_per_launch"],
+                "wave_insts_per_launch": v["wave_insts_per_launch"], "simd_busy_frac": v.get("simd_busy_frac"),
                 "algorithmic_bytes_per_launch": ab, "ms_per_launch": ms, "limited_by": BOUND.get(dom),
                 "hbm_floor": hbm, "source": "SQ_INSTS_VALU per launch from the committed rocprofv3 --pmc passes of this "
                                             "command on this scene (profiles/pmc_traffic*.json), duration live from HIP events"}
@@ -806,7 +806,12 @@ def main():
                 peak = 1024 * 0.5 * clk      # G wave-instructions / s
                 rate = v["valu_insts"] / (ent["ms"] * 1e-3) / 1e9
                 ent["valu"] = {"wave_insts_per_launch": v["valu_insts"], "achieved_Ginst_s": rate, "peak_Ginst_s": peak,
-                               "frac": rate / peak, "lds_atomic_insts": v.get("lds_atomic_insts"),
+                               "frac": rate / peak,
+                               # how full the vector pipes were: the cycles vector instructions kept their SIMD
+                               # (SQ_ACTIVE_INST_VALU, units of 4 cycles) over 1024 SIMDs x the launch's cycles
+                               "simd_busy_frac": (v["valu_active_simd_cycles"] / (1024.0 * v["launch_cycles"])
+                                                  if v.get("valu_active_simd_cycles") and v.get("launch_cycles") else None),
+                               "lds_atomic_insts": v.get("lds_atomic_insts"),
                                "insts_per_tested_pair": v["valu_insts"] * 64.0 / pairs if k.startswith("render") and pairs else None}
         views_total = world * V * args.steps
         res = {

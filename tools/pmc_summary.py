@@ -116,6 +116,13 @@ def main():
         ga = acc[k].get("GRBM_GUI_ACTIVE")
         if ga and k in dur_ns:
             ent["clock_GHz"] = (sum(ga) / len(ga)) / 8.0 / dur_ns[k]
+        # SQ_ACTIVE_INST_VALU counts, summed over the SIMDs, the time a vector instruction occupies its SIMD, in
+        # units of four cycles; with the busy cycles of the launch (GRBM_GUI_ACTIVE over the 8 XCDs) it says how
+        # full the vector pipes were, whatever the instruction mix costs per instruction
+        av = acc[k].get("SQ_ACTIVE_INST_VALU")
+        if av and ga:
+            ent["valu_active_simd_cycles"] = 4.0 * sum(av) / len(av)
+            ent["launch_cycles"] = (sum(ga) / len(ga)) / 8.0
         valu[k] = ent
     out_d["_valu"] = valu
     # bench.py defaults, which tools/collect_pmc.sh runs; another scene's file is never bench.py's default one
