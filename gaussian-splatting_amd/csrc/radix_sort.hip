@@ -559,7 +559,12 @@ __global__ void __launch_bounds__(EP_THREADS) emit_partition_kernel(const EmitPa
             const uint4 gb = a.sbin[b0 * 256 + lo[k]];
             const uint32_t q = sidx - s_off[lo[k]];
             const uint32_t rw = gb.y & 0xffffu;
-            const uint32_t ty = q / rw;
+            // q / rw without the integer division (about 25 instructions): q < the rectangle's tile count
+            // <= 2^16 here (two-digit tile ids), so the float quotient is exact or one off, and the two
+            // comparisons repair it
+            uint32_t ty = (uint32_t)((float)q * __builtin_amdgcn_rcpf((float)rw));
+            ty -= (ty * rw > q) ? 1u : 0u;
+            ty += ((ty + 1u) * rw <= q) ? 1u : 0u;
             const uint32_t tx = q - ty * rw;
             key[k] = ((gb.x >> 16) + ty) * (uint32_t)a.grid_x + (gb.x & 0xffffu) + tx;
             val[k] = gb.z;
