@@ -187,7 +187,8 @@ __device__ __forceinline__ void onesweep_tile(const K* __restrict__ kin, const u
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     K* s_keys = reinterpret_cast<K*>(smem);                               // [TILE]
     uint32_t* s_vals = reinterpret_cast<uint32_t*>(smem) + (ONE_PHASE ? TILE : 0);  // [TILE]; u64 keys: second phase
-    uint32_t* s_whist = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * 8);  // [NW][256]
+    // (packed instances are staged as keys only: the tables follow 4 bytes per pair, not 8)
+    uint32_t* s_whist = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * (PACKED ? 4 : 8));  // [NW][256]
     uint32_t* s_hist = s_whist + NW * 256;                                // [256]
     uint32_t* s_dstart = s_hist + 256;                                    // [256]
     uint32_t* s_gofs = s_dstart + 256;                                    // [256]
@@ -381,8 +382,10 @@ __device__ __forceinline__ void onesweep_tile(const K* __restrict__ kin, const u
     }
 }
 
+// (the packed pass holds no values in registers or LDS and runs four workgroups per CU; for the others a
+// fourth one costs spills: the batched depth sort 1.22 -> 1.32 ms)
 template <class K, int THREADS, int ITEMS, int BITS, bool SEG, class S = uint32_t, bool PACKED = false>
-__global__ void __launch_bounds__(THREADS, (GS_OS_BLOCKS * THREADS) / 256)
+__global__ void __launch_bounds__(THREADS, ((PACKED ? 4 : GS_OS_BLOCKS) * THREADS) / 256)
 onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __restrict__ kout,
                 uint32_t* __restrict__ vout, int64_t n, int shift, int bits, const uint32_t* __restrict__ gbase,
                 S* status, uint32_t* ticket, uint32_t* err, const SegArgs seg) {
@@ -692,6 +695,7 @@ __global__ void __launch_bounds__(EP_THREADS) emit_partition_kernel(const EmitPa
 constexpr int OS_THREADS = GS_OS_THREADS;
 constexpr int OS_ITEMS = SORT_TILE / OS_THREADS;
 constexpr size_t OS_LDS = (size_t)SORT_TILE * 8 + (OS_THREADS / 64 + 4) * 256 * 4 + 64;
+constexpr size_t OS_LDS_PACKED = (size_t)SORT_TILE * 4 + (OS_THREADS / 64 + 4) * 256 * 4 + 64;
 
 uint32_t* sort_prepare(void* temp, int64_t n, int passes, hipStream_t st, hipError_t* e) {
     const SortTemp t = sort_temp_view(temp, (size_t)(n > 0 ? n : 1), passes);
@@ -919,11 +923,12 @@ hipError_t launch_segmented_pass(int n_visible, int ntiles, int nbits, int64_t R
         if (lowbits <= 6) kern = onesweep_kernel<uint32_t, OS_THREADS, OS_ITEMS, 6, true, uint32_t, true>;
         else if (lowbits == 7) kern = onesweep_kernel<uint32_t, OS_THREADS, OS_ITEMS, 7, true, uint32_t, true>;
     }
+    const size_t lds = packed ? OS_LDS_PACKED : OS_LDS;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)OS_LDS);
+                                       (int)lds);
     if (e != hipSuccess) return e;
     const unsigned tiles = (unsigned)(R / SORT_TILE + seg.nseg + 1);  // an upper bound; the kernel knows the number
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(OS_THREADS), OS_LDS, st, (const uint32_t*)keys[1],
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(OS_THREADS), lds, st, (const uint32_t*)keys[1],
                        (const uint32_t*)vals[1], keys[0], vals[0], R, packed ? 32 - lowbits : 0, lowbits,
                        (const uint32_t*)nullptr, f.status_b,
                        f.ticket + 1, f.err, seg);
