@@ -234,3 +234,59 @@ def test_rasterizer_with_64_bit_sort_status_words(oracle):
         _compare(oracle, sc, rs, ten, True, (0, 0, 0))
     finally:
         L.gsr_test_force_wide_sort_status(0)
+
+
+@pytest.mark.parametrize("extra", [0, 1], ids=["2^25_gaussians_packed", "2^25+1_gaussians_as_pairs"])
+def test_instance_packing_at_its_limit(oracle, extra):
+    """Between the key emission and the segmented pass an instance is one word, (low tile digit << 25) |
+    Gaussian index at 1080p, as long as every index fits below the digit: 2^25 Gaussians is the last model
+    size that packs, one more takes (tile id, index) pairs.  The Gaussians that reach the screen have the
+    highest indices (all index bits in use); the rest of the model sits at the camera position and is
+    culled.  Lists, ranges and images against the checker at both sizes."""
+    W, H, nvis = 1920, 1080, 4000
+    P = (1 << 25) + extra
+    vis = synth.street_scene(nvis, W, H, seed=5, sh_coeffs=1)
+    cam = vis["camera"]
+
+    def grown(a, fill):
+        out = np.empty((P,) + a.shape[1:], np.float32)
+        out[:P - nvis] = np.asarray(fill, np.float32)
+        out[P - nvis:] = a
+        return out
+
+    sc = dict(means3D=grown(vis["means3D"], np.asarray(cam["campos"], np.float32)),   # view depth 0: culled
+              scales=grown(vis["scales"], 0.01), rotations=grown(vis["rotations"], (1.0, 0.0, 0.0, 0.0)),
+              opacities=grown(vis["opacities"], 0.5), shs=grown(vis["shs"], 0.0), reps=grown(vis["reps"], 0.0),
+              camera=cam, sh_degree=0)
+    bg = (0.2, 0.1, 0.3)
+    f = oracle.forward_from_scene(sc, bg=bg, antialiasing=True)
+    assert f.R > 0 and int((f.radii > 0).sum()) > nvis // 4 and f.point_list.min() >= P - nvis
+    rs, ten = scene_to_torch(sc, bg=bg, antialiasing=True, debug=False)
+    out = run_forward_raw(rs, ten)
+    torch.cuda.synchronize()
+    assert out["num_rendered"] == f.R
+    assert np.array_equal(out["radii"].cpu().numpy(), f.radii)
+    from _gsplat_lib import GsrLayout, lib
+    import ctypes
+    lay = GsrLayout()
+    assert lib().gsr_layout(P, W, H, f.R, ctypes.byref(lay)) == 0
+    v = (lay.vals0, lay.vals1)[lay.sorted_buffer]
+    point_list = out["binning"][v:v + 4 * f.R].cpu().numpy().view(np.uint32)
+    assert np.array_equal(point_list, f.point_list)
+    ntiles = ((W + 15) // 16) * ((H + 15) // 16)
+    img = out["img"].cpu().numpy()
+    assert np.array_equal(img[lay.ranges:lay.ranges + ntiles * 8].view(np.uint32).reshape(ntiles, 2), f.ranges)
+    assert np.array_equal(img[lay.n_contrib:lay.n_contrib + W * H * 4].view(np.uint32), f.n_contrib)
+    keys = torch.empty(f.R, dtype=torch.int64, device="cuda:0")
+    assert lib().gsr_sorted_keys_u64(P, W, H, f.R, out["geom"].data_ptr(), out["binning"].data_ptr(),
+                                     out["img"].data_ptr(), keys.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(keys.cpu().numpy().view(np.uint64), f.keys)
+    # which path ran: only the pair path stores the sorted tile ids beside the index list
+    k = (lay.keys0, lay.keys1)[lay.sorted_buffer]
+    stored = out["binning"][k:k + 4 * f.R].cpu().numpy().view(np.uint32)
+    assert np.array_equal(stored, (f.keys >> np.uint64(32)).astype(np.uint32)) == (extra == 1)
+    assert np.array_equal(out["gauss_count"].cpu().numpy(), f.gauss_count)
+    assert np.array_equal(out["last_contr_gauss"].cpu().numpy(), f.last_contr)
+    assert np.abs(out["color"].cpu().numpy() - f.out_color).max() <= ABS_TOL
+    assert np.abs(out["out_reps"].cpu().numpy() - f.out_reps).max() <= ABS_TOL * 10
