@@ -61,6 +61,17 @@ __device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t v) {
     return v;
 }
 
+// Inclusive running maximum over the 64 lanes (the same steps; lanes a step does not reach read 0).
+__device__ __forceinline__ uint32_t wave_scan_incl_max_u32(uint32_t v) {
+    v = max(v, dpp_u<0x111, 0xf>(v));  // row_shr:1
+    v = max(v, dpp_u<0x112, 0xf>(v));  // row_shr:2
+    v = max(v, dpp_u<0x114, 0xf>(v));  // row_shr:4
+    v = max(v, dpp_u<0x118, 0xf>(v));  // row_shr:8
+    v = max(v, dpp_u<0x142, 0xa>(v));  // row_bcast:15
+    v = max(v, dpp_u<0x143, 0xc>(v));  // row_bcast:31
+    return v;
+}
+
 // Lane exchanges inside a quad (DPP, no LDS): value of lane ^ 1, ^ 2.
 __device__ __forceinline__ float lane_xor1(float v) { return dpp_f<0xB1, 0xf>(v); }   // quad_perm [1,0,3,2]
 __device__ __forceinline__ float lane_xor2(float v) { return dpp_f<0x4E, 0xf>(v); }   // quad_perm [2,3,0,1]
