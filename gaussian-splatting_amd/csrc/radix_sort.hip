@@ -205,14 +205,22 @@ __device__ __forceinline__ void onesweep_tile(const K* __restrict__ kin, const u
     uint32_t my_seg = 0;
     if (SEG) {
         if (tile >= seg.tile0[seg.nseg]) return;  // the grid is an upper bound of the tiles there are
-        for (int i = tid; i < seg.nseg; i += THREADS)
-            if (seg.tile0[i] <= tile && tile < seg.tile0[i + 1]) s_tile[1] = (uint32_t)i;
+        // the thread that finds the tile's segment fetches what the others need of it in the same round trip
+        for (int i = tid; i < seg.nseg; i += THREADS) {
+            const uint32_t a0 = seg.tile0[i], a1 = seg.tile0[i + 1];
+            if (a0 <= tile && tile < a1) {
+                s_tile[1] = (uint32_t)i;
+                s_tile[2] = a0;
+                s_tile[3] = seg.start[i];
+                s_tile[4] = seg.start[i + 1];
+            }
+        }
         __syncthreads();
         my_seg = s_tile[1];
-        const uint32_t t0 = seg.tile0[my_seg];
+        const uint32_t t0 = s_tile[2];
         first_tile = tile == t0;
-        tile_base = (int64_t)seg.start[my_seg] + (int64_t)(tile - t0) * TILE;
-        n = seg.start[my_seg + 1];
+        tile_base = (int64_t)s_tile[3] + (int64_t)(tile - t0) * TILE;
+        n = s_tile[4];
     }
     const int64_t wave_base = tile_base + (int64_t)w * (64 * ITEMS);
     const uint32_t dmask = (1u << bits) - 1;
