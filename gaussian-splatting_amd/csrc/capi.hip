@@ -327,16 +327,17 @@ int gsr_preprocess_batch(const GsrScene* s, int nviews, GsrForwardView* views, v
     GSR_TRY(launch_preprocess_fwd_batch(*s, nviews, views, st));
     mark(s, GSR_EV_FWD_BATCH, st);
     // prefix sums of every view, then all the totals with one host block
-    constexpr int CHUNK = 16;
+    // (the scans of up to 16 views in one launch, their totals collected for one copy)
+    constexpr int CHUNK = SCAN_BATCH_MAX;
     for (int v0 = 0; v0 < nviews; v0 += CHUNK) {
         const int n = nviews - v0 < CHUNK ? nviews - v0 : CHUNK;
         uint64_t tot[CHUNK][3];
-        for (int k = 0; k < n; ++k) {
-            const GeomBuf g = geom_buf(views[v0 + k].geom_buffer, (size_t)s->P);
-            GSR_TRY(launch_scan_blocks(g, (s->P + PRE_BLOCK - 1) / PRE_BLOCK, st));
-            if (hipMemcpyAsync(tot[k], g.total, sizeof(tot[k]), hipMemcpyDeviceToHost, st) != hipSuccess)
-                return GSR_ERR_HIP;
-        }
+        GeomBuf gb[CHUNK];
+        for (int k = 0; k < n; ++k) gb[k] = geom_buf(views[v0 + k].geom_buffer, (size_t)s->P);
+        uint64_t* all = nullptr;
+        GSR_TRY(launch_scan_blocks_batch(n, gb, (s->P + PRE_BLOCK - 1) / PRE_BLOCK, st, &all));
+        if (hipMemcpyAsync(tot, all, (size_t)n * sizeof(tot[0]), hipMemcpyDeviceToHost, st) != hipSuccess)
+            return GSR_ERR_HIP;
         if (hipStreamSynchronize(st) != hipSuccess) return GSR_ERR_HIP;
         for (int k = 0; k < n; ++k) {
             if (tot[k][1]) return GSR_ERR_OVERFLOW;

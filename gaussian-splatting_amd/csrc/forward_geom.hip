@@ -332,8 +332,9 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_batch_kernel(const P
 constexpr int SCAN_THREADS = 1024, SCAN_ITEMS = 32;
 // Workgroup 1, if launched, scans a second array the same way (the per-block
 // counts of Gaussians with instances) and writes its total into total[2].
-__global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* sums0, uint32_t* sums1, int nb,
-                                                                   uint64_t* total) {
+// `all`, if given: the three totals once more, where the totals of several views are collected.
+__device__ __forceinline__ void scan_blocks_body(uint32_t* sums0, uint32_t* sums1, int nb, uint64_t* total,
+                                                 uint64_t* all) {
     __shared__ uint64_t s_wave[SCAN_THREADS / 64];
     uint32_t* block_sums = blockIdx.x == 0 ? sums0 : sums1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -404,10 +405,33 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* sum
         if (blockIdx.x == 0) {
             total[0] = carry;
             total[1] = carry > 0x7fffffffull ? 1 : 0;
+            if (all) {
+                all[0] = total[0];
+                all[1] = total[1];
+            }
         } else {
             total[2] = carry;
+            if (all) all[2] = carry;
         }
     }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* sums0, uint32_t* sums1, int nb,
+                                                                   uint64_t* total) {
+    scan_blocks_body(sums0, sums1, nb, total, nullptr);
+}
+
+// The scans of several views in one launch (blockIdx.y = view); every view's totals also go to
+// all[3 * view ..], so that the host fetches them with one copy.
+struct ScanBatchArgs {
+    uint32_t* sums0[SCAN_BATCH_MAX];
+    uint32_t* sums1[SCAN_BATCH_MAX];
+    uint64_t* total[SCAN_BATCH_MAX];
+    uint64_t* all;
+};
+__global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_batch_kernel(const ScanBatchArgs b, int nb) {
+    const int v = blockIdx.y;
+    scan_blocks_body(b.sums0[v], b.sums1[v], nb, b.total[v], b.all + 3 * v);
 }
 
 // Depth keys for ordering the Gaussians front to back: the f32 bits of the
@@ -797,6 +821,20 @@ hipError_t launch_preprocess_fwd_batch(const GsrScene& s, int nviews, const GsrF
 
 hipError_t launch_scan_blocks(const GeomBuf& g, int nb, hipStream_t st) {
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(2), dim3(SCAN_THREADS), 0, st, g.block_sums, g.vis_sums, nb, g.total);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_blocks_batch(int count, const GeomBuf* g, int nb, hipStream_t st, uint64_t** all) {
+    if (count <= 0 || count > SCAN_BATCH_MAX) return hipErrorInvalidValue;
+    ScanBatchArgs b;
+    for (int i = 0; i < count; ++i) {
+        b.sums0[i] = g[i].block_sums;
+        b.sums1[i] = g[i].vis_sums;
+        b.total[i] = g[i].total;
+    }
+    b.all = g[0].total + 4;   // behind the first view's own totals
+    *all = b.all;
+    hipLaunchKernelGGL(scan_blocks_batch_kernel, dim3(2, count), dim3(SCAN_THREADS), 0, st, b, nb);
     return hipGetLastError();
 }
 

@@ -10,6 +10,8 @@
 namespace gs {
 
 // Geometry buffer with the extra per-Gaussian arrays this implementation keeps.
+constexpr int SCAN_BATCH_MAX = 16;   // views whose prefix scans share a launch
+
 struct GeomBuf {
     SplatRec* rec;        // [P]
     float* cov3D;         // [P,6]
@@ -20,7 +22,8 @@ struct GeomBuf {
     uint8_t* clamped;     // [P]
     uint32_t* block_sums; // [nblocks+1] tiles per block of 256 Gaussians in index order (gives the total)
     uint32_t* vis_sums;   // [nblocks+1] Gaussians with instances per block, then exclusive offsets
-    uint64_t* total;      // [4] instances, overflow flag, Gaussians with instances
+    uint64_t* total;      // [4] instances, overflow flag, Gaussians with instances; then [3 * SCAN_BATCH_MAX]: the
+                          // same three of every view whose scans ran in one launch with this view as the first
     uint32_t* dkeys[2];   // [P] depth bits (all ones for Gaussians that are not rendered), ping-pong
     uint32_t* dvals[2];   // [P] Gaussian index, ping-pong; the sorted one is the front-to-back order
     uint4* sbin;          // [P] {x0 | y0<<16, w | h<<16, Gaussian index, tiles} in front-to-back order
@@ -43,7 +46,7 @@ inline GeomBuf geom_buf(const void* base, size_t P) {
     v.clamped = (uint8_t*)take(P);
     v.block_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));
     v.vis_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));
-    v.total = (uint64_t*)take(4 * sizeof(uint64_t));
+    v.total = (uint64_t*)take((4 + 3 * SCAN_BATCH_MAX) * sizeof(uint64_t));
     v.dkeys[0] = (uint32_t*)take(P * sizeof(uint32_t));
     v.dkeys[1] = (uint32_t*)take(P * sizeof(uint32_t));
     v.dvals[0] = (uint32_t*)take(P * sizeof(uint32_t));
@@ -75,6 +78,8 @@ hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, cons
 hipError_t launch_preprocess_fwd_batch(const GsrScene& s, int nviews, const GsrForwardView* views, hipStream_t st);
 // Exclusive scans of the per-block tile sums and visible counts; totals into g.total.
 hipError_t launch_scan_blocks(const GeomBuf& g, int nb, hipStream_t st);
+// The same for `count` views (at most SCAN_BATCH_MAX) in one launch; *all: device array of 3 totals per view.
+hipError_t launch_scan_blocks_batch(int count, const GeomBuf* g, int nb, hipStream_t st, uint64_t** all);
 // Depth keys of the n Gaussians to order (n = number with instances: compacted; n = P: all of them),
 // sorted front to back (stable): g.dvals[*order_buffer][0..n) is the order.
 hipError_t launch_depth_order(const GeomBuf& g, int P, int n, hipStream_t st, int* order_buffer);
