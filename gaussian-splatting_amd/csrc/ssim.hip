@@ -9,7 +9,9 @@
 // compute four neighbouring outputs per thread from a sliding window of 14
 // inputs, which cuts the LDS reads per output from 11 to 3.5 (the kernels were
 // bound by LDS reads and barriers, not by the 6 / 7 planes of HBM traffic);
-// every output still accumulates its taps in the order G_00..G_10.
+// every output still accumulates its taps in the order G_00..G_10, one fused multiply-add per tap (the
+// library is built without floating-point contraction, so the fusion is written out; the reference's
+// taps are contracted to FMAs by its compiler as well).
 #include "kernels.h"
 
 namespace gs {
@@ -64,11 +66,11 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, float C1, f
                 const int k = j - r;  // output lx + r sees this input as its tap k
                 if (k >= 0 && k < GS_SSIM_TAPS) {
                     const float g = ssim_tap(k);
-                    v[0][r] += g * pa;
-                    v[1][r] += g * aa;
-                    v[2][r] += g * pb;
-                    v[3][r] += g * bb;
-                    v[4][r] += g * ab;
+                    v[0][r] = fmaf(g, pa, v[0][r]);
+                    v[1][r] = fmaf(g, aa, v[1][r]);
+                    v[2][r] = fmaf(g, pb, v[2][r]);
+                    v[3][r] = fmaf(g, bb, v[3][r]);
+                    v[4][r] = fmaf(g, ab, v[4][r]);
                 }
             }
         }
@@ -94,7 +96,7 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, float C1, f
             if (k >= 0 && k < GS_SSIM_TAPS) {
                 const float g = ssim_tap(k);
 #pragma unroll
-                for (int c = 0; c < 5; ++c) v[c][r] += g * in[c];
+                for (int c = 0; c < 5; ++c) v[c][r] = fmaf(g, in[c], v[c][r]);
             }
         }
     }
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, const float
                 if (k >= 0 && k < GS_SSIM_TAPS) {
                     const float g = ssim_tap(k);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) v[c][r] += g * in[c];
+                    for (int c = 0; c < 3; ++c) v[c][r] = fmaf(g, in[c], v[c][r]);
                 }
             }
         }
@@ -232,7 +234,7 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, const float
             if (k >= 0 && k < GS_SSIM_TAPS) {
                 const float g = ssim_tap(k);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) v[c][r] += g * in[c];
+                for (int c = 0; c < 3; ++c) v[c][r] = fmaf(g, in[c], v[c][r]);
             }
         }
     }

@@ -701,7 +701,7 @@ static void sep_conv(const float* in, float* out, int H, int W, std::vector<floa
             for (int k = 0; k < GS_SSIM_TAPS; ++k) {
                 const int xx = x + k - 5;
                 const float p = (xx >= 0 && xx < W) ? in[(size_t)y * W + xx] : 0.0f;
-                v += ssim_tap(k) * p;
+                v = fmaf(ssim_tap(k), p, v);   // one fused multiply-add per tap, as the kernels
             }
             tmp[(size_t)y * W + x] = v;
         }
@@ -711,7 +711,7 @@ static void sep_conv(const float* in, float* out, int H, int W, std::vector<floa
             for (int k = 0; k < GS_SSIM_TAPS; ++k) {
                 const int yy = y + k - 5;
                 const float p = (yy >= 0 && yy < H) ? tmp[(size_t)yy * W + x] : 0.0f;
-                v += ssim_tap(k) * p;
+                v = fmaf(ssim_tap(k), p, v);   // one fused multiply-add per tap, as the kernels
             }
             out[(size_t)y * W + x] = v;
         }
