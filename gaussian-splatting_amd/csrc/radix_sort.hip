@@ -21,6 +21,12 @@ constexpr uint32_t ST_AGG = 1u << 30;   // tile count published
 constexpr uint32_t ST_INCL = 2u << 30;  // inclusive prefix published
 constexpr uint32_t ST_MASK = (1u << 30) - 1;
 // The same three for a status word of type S (u32: counts below 2^30; u64: any count a u32 position can reach).
+// peers & ~(ballot ^ mine) as ONE three-input bit operation (truth table 0x90 = a & ~(b ^ c)); written
+// as an expression the compiler splits it into an xor per bit and an or over three of them.
+__device__ __forceinline__ uint32_t keep_equal_bits(uint32_t peers, uint32_t ballot, uint32_t mine) {
+    return __builtin_amdgcn_bitop3_b32(peers, ballot, mine, 0x90);
+}
+
 template <class S> struct St {
     static constexpr S AGG = (S)1 << (sizeof(S) * 8 - 2);
     static constexpr S INCL = (S)2 << (sizeof(S) * 8 - 2);
@@ -273,8 +279,8 @@ __device__ __forceinline__ void onesweep_tile(const K* __restrict__ kin, const u
             uint32_t m = (uint32_t)(((int32_t)(d << (31 - b))) >> 31);
             asm("" : "+v"(m));  // the ballot compares m itself, not a second extraction of the bit
             const uint64_t bal = __builtin_amdgcn_ballot_w64(m != 0);
-            plo &= ~((uint32_t)bal ^ m);
-            phi &= ~((uint32_t)(bal >> 32) ^ m);
+            plo = keep_equal_bits(plo, (uint32_t)bal, m);
+            phi = keep_equal_bits(phi, (uint32_t)(bal >> 32), m);
         }
         const uint32_t lower = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
         const uint32_t cnt = __popc(plo) + __popc(phi);
@@ -640,8 +646,8 @@ __global__ void __launch_bounds__(EP_THREADS) emit_partition_kernel(const EmitPa
             uint32_t m = (uint32_t)(((int32_t)(d << (31 - bit))) >> 31);
             asm("" : "+v"(m));
             const uint64_t bal = __builtin_amdgcn_ballot_w64(m != 0);
-            plo &= ~((uint32_t)bal ^ m);
-            phi &= ~((uint32_t)(bal >> 32) ^ m);
+            plo = keep_equal_bits(plo, (uint32_t)bal, m);
+            phi = keep_equal_bits(phi, (uint32_t)(bal >> 32), m);
         }
         const uint32_t lower = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
         const uint32_t cnt_same = __popc(plo) + __popc(phi);
