@@ -522,7 +522,10 @@ __global__ void __launch_bounds__(EP_THREADS) emit_partition_kernel(const EmitPa
     __shared__ uint32_t s_first;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) s_chunk = atomicAdd(a.ticket, 1u);
+    if (tid == 0) {
+        s_chunk = atomicAdd(a.ticket, 1u);
+        s_first = 1u;   // entry 0, should the tables not name the entry of the first instance (every index stays in range)
+    }
     for (int i = tid; i < (NW + 1) * NB; i += EP_THREADS) s_whist[i] = 0;
     for (int i = tid; i < EP_CHUNK / 2; i += EP_THREADS) reinterpret_cast<uint32_t*>(s_mark)[i] = 0;
     __syncthreads();
