@@ -164,3 +164,18 @@ def tiny_scene(P=64, width=40, height=24, seed=7, sh_coeffs=16, dim=4, spread=1.
     cam = make_camera(width, height, 0.9, (0.1, -0.05, -2.5), (0.0, 0.0, 1.0))
     return dict(means3D=xyz, scales=scales, rotations=rot, opacities=opac.reshape(P, 1), shs=sh, reps=reps,
                 camera=cam, sh_degree=int(round(math.sqrt(sh_coeffs))) - 1)
+
+
+def deep_scene(P=480, width=56, height=40, seed=31, sh_coeffs=16, dim=4, high_share=0.15):
+    """Long lists on a few tiles: most splats are nearly transparent (opacity 0.01 .. 0.06), so a pixel
+    blends dozens of them, and every few entries comes one with opacity 0.9 .. 1.0 (alpha up to the
+    0.99 clamp), the case in which the backward's T / (1 - alpha) amplifies an error in alpha most.
+    Everything sits in front of the camera, depths interleaved."""
+    sc = tiny_scene(P=P, width=width, height=height, seed=seed, sh_coeffs=sh_coeffs, dim=dim, spread=0.8, scale=0.10)
+    rng = np.random.default_rng(seed + 500)
+    sc["means3D"][:, 2] = (0.5 + 3.0 * rng.random(P)).astype(np.float32)
+    op = (0.01 + 0.05 * rng.random(P)).astype(np.float32)
+    high = rng.random(P) < high_share
+    op[high] = (0.9 + 0.1 * rng.random(int(high.sum()))).astype(np.float32)
+    sc["opacities"] = op.reshape(P, 1)
+    return sc

@@ -5,6 +5,11 @@
                                                     statistics invariants on the kernel output
   C3  6 M Gaussians, 1297x840, antialiasing,        full comparison, forward and backward,
       forward + fused-ssim + backward               plus the ssim kernels on the rendered image
+  C2t / C3t  the same two on the translucent        deep lists: the pixels blend a large part of every tile
+      variant of the scene                          list (the street scene saturates after a few per cent),
+                                                    the forward kernel with quadrant reach masks is the one
+                                                    the library picks, T / (1 - alpha) is recovered dozens to
+                                                    hundreds of times in a row per pixel in the backward
   C4  6 M Gaussians, 1920x1080, 8 cameras,          the step as bench.py runs it (batched forward preprocess,
       one multi-view step on one GPU                views on 3 streams, deferred backward) against the plain
                                                     per-view path; one of the views in full against the CPU checker
@@ -24,7 +29,7 @@ import pytest
 import torch
 
 import synth
-from gpu_util import read_internals, rel_err, run_forward_raw, scene_to_torch
+from gpu_util import read_internals, rel_err, run_forward_raw, scene_to_torch, worst
 from test_gpu_rasterizer import ABS_TOL, REL_TOL, _check_forward, _grads_gpu
 
 pytestmark = pytest.mark.gpu
@@ -57,8 +62,8 @@ def test_c2_render_2p5M_1080p(oracle):
     assert f.R > 5_000_000
 
 
-def test_c2_fork_statistics_invariants_on_the_kernel_output():
-    """The fork's extra outputs at C2 size, on what the HIP kernels produce (no checker involved).
+def _fork_statistics_invariants(out, P, W, H):
+    """The fork's extra outputs on what the HIP kernels produce (no checker involved).
     The fork author's own test (diff_gaussian_rasterization/__init__.py:130-147) compares, for one
     Gaussian, the mean final transmittance of the pixels it contributed to last with
     gauss_sum / gauss_count; that equality needs the alternate accumulation the author left
@@ -69,11 +74,6 @@ def test_c2_fork_statistics_invariants_on_the_kernel_output():
         sum of accum_alpha over those pixels <= gauss_sum[g];
       * T <= 1:  gauss_sum[g] <= gauss_count[g];  one is zero exactly when the other is;
       * a pixel nothing contributed to has last_contr_gauss == -1 and accum_alpha == 1."""
-    P, W, H = 2_500_000, 1920, 1080
-    sc = synth.street_scene(P, W, H, seed=2)
-    rs, ten = scene_to_torch(sc, antialiasing=False, debug=False)
-    out = run_forward_raw(rs, ten)
-    torch.cuda.synchronize()
     last = out["last_contr_gauss"].view(-1).long()
     T = out["accum_alpha"].view(-1)
     gsum, gcnt = out["gauss_sum"].double(), out["gauss_count"].long()
@@ -97,8 +97,56 @@ def test_c2_fork_statistics_invariants_on_the_kernel_output():
     assert int(hit.sum()) > W * H // 2 and int((pix_per_g > 0).sum()) > 1_000
 
 
-def test_c3_train_step_6M_1297x840(oracle):
-    sc = synth.street_scene(6_000_000, 1297, 840, seed=3)
+def test_c2_fork_statistics_invariants_on_the_kernel_output():
+    P, W, H = 2_500_000, 1920, 1080
+    sc = synth.street_scene(P, W, H, seed=2)
+    rs, ten = scene_to_torch(sc, antialiasing=False, debug=False)
+    out = run_forward_raw(rs, ten)
+    torch.cuda.synchronize()
+    _fork_statistics_invariants(out, P, W, H)
+
+
+def _walked_fraction(f, W, H):
+    """Share of the sorted instances that lie in front of the last entry some pixel of their tile blended
+    (what the blend kernels walk), from the checker's n_contrib and ranges."""
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    nc = np.zeros((gy * 16, gx * 16), np.int64)
+    nc[:H, :W] = f.n_contrib.reshape(H, W)
+    per_tile = nc.reshape(gy, 16, gx, 16).max(axis=(1, 3)).reshape(-1)
+    return float(per_tile.sum()) / max(1, f.R), per_tile
+
+
+def test_c2_translucent_render_2p5M_1080p_deep_lists(oracle):
+    """C2 on the translucent variant of the scene (small, mostly transparent splats): every pixel blends a
+    large part of its tile's list.  The library's own choice of forward kernel must be the one with
+    quadrant reach masks here (fewer than six tiles per rendered Gaussian); the plain kernel and the
+    (tile id, index) pair path are forced after it; all against the checker, then the fork-statistics
+    invariants on the kernel output."""
+    from _gsplat_lib import lib
+    P, W, H = 2_500_000, 1920, 1080
+    sc = synth.street_scene(P, W, H, seed=2, translucent=True)
+    t0 = time.time()
+    f, out, rs, ten, _ = _check_forward(oracle, sc, False, (0.0, 0.0, 0.0))
+    vis = int((f.radii > 0).sum())
+    assert f.R < 6 * vis, "the library picks the reach-mask forward kernel when R < 6 * visible"
+    frac, per_tile = _walked_fraction(f, W, H)
+    print(f"C2t: R={f.R}, visible={vis}, walked {frac:.2f} of R, deepest walk {int(per_tile.max())} entries, "
+          f"{time.time() - t0:.1f}s")
+    assert frac > 0.25 and int(per_tile.max()) > 1000     # deep lists, not the street scene's 3 %
+    _fork_statistics_invariants(out, P, W, H)
+    try:
+        lib().gsr_test_forward_reach_masks(0)
+        _check_forward(oracle, sc, False, (0.0, 0.0, 0.0))
+    finally:
+        lib().gsr_test_forward_reach_masks(-1)
+    try:
+        lib().gsr_test_packed_instances(0)
+        _check_forward(oracle, sc, False, (0.0, 0.0, 0.0), packed_pairs=False)
+    finally:
+        lib().gsr_test_packed_instances(1)
+
+
+def _c3_train_step(oracle, sc, tag):
     t0 = time.time()
     f, out, rs, ten, kw_g = _check_forward(oracle, sc, True, (0.0, 0.0, 0.0))
     t1 = time.time()
@@ -125,8 +173,26 @@ def test_c3_train_step_6M_1297x840(oracle):
     for k in got:
         r = ref[k].reshape(got[k].shape)
         assert np.isfinite(got[k]).all(), k
-        assert rel_err(got[k], r) <= REL_TOL, (k, rel_err(got[k], r))
-    print(f"C3: R={f.R}, forward {t1 - t0:.1f}s, backward {t2 - t1:.1f}s")
+        assert rel_err(got[k], r) <= REL_TOL, (k, rel_err(got[k], r), worst(got[k], r))
+    frac, per_tile = _walked_fraction(f, W, H)
+    print(f"{tag}: R={f.R}, walked {frac:.2f} of R (deepest {int(per_tile.max())}), forward {t1 - t0:.1f}s, "
+          f"backward {t2 - t1:.1f}s")
+    return f, frac, per_tile
+
+
+def test_c3_train_step_6M_1297x840(oracle):
+    _c3_train_step(oracle, synth.street_scene(6_000_000, 1297, 840, seed=3), "C3")
+
+
+def test_c3_translucent_train_step_6M_1297x840_deep_lists(oracle):
+    """C3 on the translucent variant: forward + loss + backward with every gradient element-wise within
+    1e-4 of the checker where the backward recovers T by a division per blended Gaussian hundreds of
+    times in a row along a pixel's list (backward.cu:591-684), with the hardware exponential and the
+    Newton-corrected reciprocal of the HIP kernel."""
+    sc = synth.street_scene(6_000_000, 1297, 840, seed=3, translucent=True)
+    f, frac, per_tile = _c3_train_step(oracle, sc, "C3t")
+    assert f.R < 6 * int((f.radii > 0).sum())        # forward: the reach-mask kernel
+    assert frac > 0.25 and int(per_tile.max()) > 1000
 
 
 def test_c4_multi_view_step_6M_1080p(oracle):

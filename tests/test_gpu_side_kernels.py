@@ -182,6 +182,25 @@ def test_fused_losses_match_the_reference_composition():
         assert np.allclose(rep.grad.cpu().numpy(), fx[f"gradrep_{i}"], rtol=1e-6, atol=0)
 
 
+def test_fused_ssim_matches_the_reference_conv2d_ssim_fixture():
+    """The HIP fused-ssim kernels straight against tests/golden/ssim_ref.npz: values and autograd gradients
+    of the reference's own utils/loss_utils.ssim (conv2d formulation) on three image pairs, written by
+    tests/golden/make_fixtures.py from the reference.  The check submodules/fused-ssim/tests/test.py:82-91
+    makes between the two, without the CPU checker in between."""
+    import os
+    from fused_ssim import fused_ssim
+    from gpu_util import rel_err
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ssim_ref.npz"))
+    for i in range(3):
+        a = torch.tensor(fx[f"img1_{i}"], device="cuda:0", requires_grad=True)
+        b = torch.tensor(fx[f"img2_{i}"], device="cuda:0")
+        val = fused_ssim(a, b)
+        val.backward()
+        assert abs(float(val) - float(fx[f"ssim_{i}"])) <= 2e-6
+        assert rel_err(a.grad.cpu().numpy(), fx[f"grad_{i}"]) <= 1e-4
+        assert abs(float(fused_ssim(a.detach(), b, train=False)) - float(fx[f"ssim_{i}"])) <= 2e-6
+
+
 @pytest.mark.parametrize("n,end_bit", [(4097, 47), (100_003, 45), (300_000, 64)])
 def test_sort_with_64_bit_status_words(oracle, n, end_bit):
     """Sorts of 2^30 pairs and more publish their look-back prefixes in 64-bit status words (a 32-bit word has

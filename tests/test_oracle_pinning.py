@@ -129,6 +129,37 @@ def test_forward_and_backward_match_dense_autograd(oracle, aa, seed):
         assert rel_err(g[b].reshape(ref.shape), ref) <= 1e-4, (a, rel_err(g[b].reshape(ref.shape), ref))
 
 
+def test_deep_lists_with_high_alpha_entries_match_dense_autograd(oracle):
+    """Dozens of blended entries per pixel, among them splats with alpha in 0.9 .. 0.99 (the list depth and
+    the alpha range in which recovering T by division in the backward, backward.cu:615, is least forgiving)."""
+    from dense_ref import dense_render
+    sc = synth.deep_scene()
+    bg = (0.3, 0.6, 0.1)
+    f = oracle.forward_from_scene(sc, bg=bg, antialiasing=True)
+    nb = _blended_per_pixel(f)
+    assert np.median(nb) >= 24 and nb.max() >= 60
+    inp = _leaves(sc, f.P)
+    out = dense_render(inp, sc["camera"], bg, sc["sh_degree"], antialiasing=True, ref_quirks=True)
+    assert np.array_equal(out["radii"].numpy(), f.radii)
+    assert np.array_equal(out["n_contrib"].numpy().reshape(-1), f.n_contrib)
+    assert np.array_equal(out["gauss_count"].numpy(), f.gauss_count)
+    assert np.abs(out["color"].detach().numpy() - f.out_color).max() < 1e-5
+    rng = np.random.default_rng(3)
+    gc, gd, gr = rng.standard_normal((3, f.H, f.W)), rng.standard_normal((1, f.H, f.W)), rng.standard_normal((4, f.H, f.W))
+    ((out["color"] * torch.tensor(gc)).sum() + (out["invdepth"] * torch.tensor(gd)).sum() +
+     (out["reps"] * torch.tensor(gr)).sum()).backward()
+    g = f.backward(gc.astype(np.float32), gd.astype(np.float32), gr.astype(np.float32))
+    for a, b in (("means3D", "dL_dmean3D"), ("means2D", "dL_dmean2D"), ("scales", "dL_dscale"),
+                 ("rotations", "dL_drot"), ("opacities", "dL_dopacity"), ("shs", "dL_dsh"), ("reps", "dL_dreps")):
+        ref = inp[a].grad.numpy()
+        assert rel_err(g[b].reshape(ref.shape), ref) <= 1e-4, (a, rel_err(g[b].reshape(ref.shape), ref))
+
+
+def _blended_per_pixel(f):
+    """How many list entries each pixel walks up to its last contributor (n_contrib is a 1-based position)."""
+    return f.n_contrib.astype(np.int64)
+
+
 def test_backward_is_the_true_gradient_where_the_reference_is_exact(oracle):
     """Without antialiasing, and for Gaussians inside the 1.3 x frustum, the
     reference backward is the exact derivative: compare with plain autograd."""
