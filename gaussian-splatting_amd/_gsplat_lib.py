@@ -53,7 +53,7 @@ class GsrForwardView(C.Structure):
 
 
 class GsrLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("rec", "cov3D", "tiles", "clamped", "block_sums", "total", "final_T",
+    _fields_ = [(n, C.c_size_t) for n in ("rec", "cov3D", "tiles", "clamped", "block_sums", "total", "depth_sort", "final_T",
                                           "n_contrib", "ranges", "keys0", "keys1", "vals0", "vals1")] + \
                [("sorted_buffer", C.c_int)]
 
@@ -91,6 +91,8 @@ def lib():
     L.gsr_test_packed_instances.argtypes = [C.c_int]
     L.gsr_test_inject_sort_error.restype = None
     L.gsr_test_inject_sort_error.argtypes = [C.c_int]
+    L.gsr_sort_noalloc_error.restype = C.c_int
+    L.gsr_sort_noalloc_error.argtypes = [_vp, C.POINTER(C.c_uint32)]
     L.gsr_forward_stage1.restype = C.c_int
     L.gsr_forward_stage1.argtypes = [C.POINTER(GsrScene), C.POINTER(GsrForwardOut), _vp, C.POINTER(C.c_int64)]
     L.gsr_forward_stage2.restype = C.c_int
@@ -174,7 +176,7 @@ def lib():
 EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backward_work_bytes",
             "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_backward_blend",
             "gsr_backward_geometry_batch", "gsr_backward_geometry_batch_range", "gsr_preprocess_batch", "gsr_mark_visible", "gsr_sort_temp_bytes", "gsr_sort_temp_error_offset", "gsr_test_inject_sort_error", "gsr_test_force_wide_sort_status", "gsr_test_forward_reach_masks", "gsr_test_packed_instances",
-            "gsr_sort_pairs_u64_u32", "gsr_sort_noalloc_max_pairs", "gsr_sort_pairs_u64_u32_noalloc", "gsr_layout", "gsr_sorted_keys_u64", "gsk_dist2_temp_bytes", "gsk_dist2", "gss_ssim_forward",
+            "gsr_sort_pairs_u64_u32", "gsr_sort_noalloc_max_pairs", "gsr_sort_pairs_u64_u32_noalloc", "gsr_sort_noalloc_error", "gsr_layout", "gsr_sorted_keys_u64", "gsk_dist2_temp_bytes", "gsk_dist2", "gss_ssim_forward",
             "gss_ssim_backward", "gss_loss_partial_floats", "gss_l1_ssim_loss_forward", "gss_l1_ssim_loss_backward",
             "gss_l1_partial_floats", "gss_l1_loss_forward", "gss_l1_loss_backward",
             "gso_adam_update", "gso_densify_stats", "gso_densify_select", "gso_mark_nonzero", "gso_prune_mask", "gso_split_children", "gso_compact_temp_bytes", "gso_compact_map",
@@ -202,12 +204,13 @@ def profile_events():
 
 
 class SortErrorWords:
-    """Where the sort's error word of every forward call lands without making the host wait.
+    """Where the sorts' error words of every forward call land without making the host wait.
 
-    The look-back spins of the radix sort are bounded; a tripped limit leaves an error word on the
+    The look-back spins of the radix sorts are bounded; a tripped limit leaves an error word on the
     device and an invalid instance list.  Each `rasterize_gaussians` call hands stage 2 one word of
     pinned host memory (GsrForwardOut.sort_error_host), preset to all ones; the last kernel of the
-    forward stores the error word there.  Every later call into the rasterizer looks at the words
+    forward stores there the error word of the instance sort OR-ed with that of the view's depth
+    order (whichever call made the order: stage 2 itself or gsr_preprocess_batch).  Every later call into the rasterizer looks at the words
     that have arrived and raises if one is set, so the failure surfaces at the next call after the
     GPU got there instead of never.  No events, no copies, nothing the stream waits on."""
 

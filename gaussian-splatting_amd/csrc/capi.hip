@@ -1,16 +1,17 @@
 // extern "C" entry points of libgsplat_amd.so (declared in include/gsplat_amd.h).
 // Host orchestration only: argument checks, scratch-buffer carving, kernel
-// launches on the caller's stream.  Re-entrant, no globals, no allocation.
-#include <atomic>
-
+// launches on the caller's stream.  Re-entrant, no allocation.  The only state the library keeps
+// between calls: the test hooks below, which are per calling thread (a hook set in one thread
+// changes nothing for calls made from another), and the per-device address of the array behind
+// gsr_sort_pairs_u64_u32_noalloc (radix_sort.hip).
 #include "kernels.h"
 
 using namespace gs;
 
 namespace {
 
-std::atomic<int> g_inject_sort_error{0};  // test hook only (gsr_test_inject_sort_error)
-std::atomic<int> g_packed_sort{1};        // test hook only (gsr_test_packed_instances)
+thread_local int t_inject_sort_error = 0;  // test hook only (gsr_test_inject_sort_error): 1 instance sort, 2 depth sort
+thread_local int t_packed_sort = 1;        // test hook only (gsr_test_packed_instances)
 
 inline int hip_status(hipError_t e) { return e == hipSuccess ? GSR_OK : GSR_ERR_HIP; }
 
@@ -76,8 +77,8 @@ size_t gsr_sort_temp_error_offset(void) {
 }
 void gsr_test_force_wide_sort_status(int on) { sort_set_force_wide(on != 0); }
 void gsr_test_forward_reach_masks(int mode) { render_fwd_set_reach_masks(mode); }
-void gsr_test_inject_sort_error(int on) { g_inject_sort_error.store(on ? 1 : 0, std::memory_order_relaxed); }
-void gsr_test_packed_instances(int on) { g_packed_sort.store(on ? 1 : 0, std::memory_order_relaxed); }
+void gsr_test_inject_sort_error(int which) { t_inject_sort_error = which == 2 ? 2 : (which ? 1 : 0); }
+void gsr_test_packed_instances(int on) { t_packed_sort = on ? 1 : 0; }
 size_t gsr_sort_temp_bytes(int64_t n) { return sort_temp_view(nullptr, (size_t)(n > 0 ? n : 1), SORT_MAX_PASSES).bytes; }
 
 int gsr_forward_stage1(const GsrScene* s, GsrForwardOut* o, void* stream, int64_t* num_rendered) {
@@ -95,7 +96,9 @@ int gsr_forward_stage1(const GsrScene* s, GsrForwardOut* o, void* stream, int64_
     mark(s, GSR_EV_STAGE1_BEGIN, st);
     if (!o->preprocessed) GSR_TRY(launch_preprocess_fwd(*s, *o, g, st));
     mark(s, GSR_EV_PREPROCESS, st);
-    GSR_TRY(launch_scan_blocks(g, (s->P + PRE_BLOCK - 1) / PRE_BLOCK, st));
+    // gsr_preprocess_batch has run this view's prefix sums already (they are in place: a second scan
+    // would scan offsets) and left its three totals in g.total; only the copy is repeated then
+    if (!o->preprocessed) GSR_TRY(launch_scan_blocks(g, (s->P + PRE_BLOCK - 1) / PRE_BLOCK, st));
     mark(s, GSR_EV_SCAN, st);
     uint64_t tot[3] = {0, 0, 0};
     if (hipMemcpyAsync(tot, g.total, sizeof(tot), hipMemcpyDeviceToHost, st) != hipSuccess) return GSR_ERR_HIP;
@@ -144,7 +147,7 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
         const bool fused = from_rects && fused_sort_fits(R, n, nbits);
         // ... and when every Gaussian index fits beside the low digit in 32 bits, an instance is one word
         // between the two kernels instead of a (tile id, index) pair
-        const bool packed = fused && fused_sort_packs(s->P, nbits) && g_packed_sort.load(std::memory_order_relaxed);
+        const bool packed = fused && fused_sort_packs(s->P, nbits) && t_packed_sort;
         if (fused) {
             uint32_t *ghist, *seg_start, *seg_tile0;
             int lowshift, lowbits;
@@ -187,24 +190,30 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
     // The sorts' look-back spins are bounded; a tripped limit sets an error word in the sort's temp area.
     // With debug the call waits and reports it; otherwise the last kernel stores the word to the caller's
     // host word in stream order (nothing here waits), or it stays unread if the caller gave none.
-    const uint32_t* sort_err = nullptr;
+    // Two sorts ran for this view when it has instances: the instance sort (error word in the binning
+    // buffer's sort area) and the front-to-back order of the Gaussians (error word in the geometry buffer's
+    // sort area, written by this call or, for preprocessed == 2, by gsr_preprocess_batch).
+    const uint32_t *sort_err = nullptr, *depth_err = nullptr;
     if (R > 0 && s->P > 0) {
-        const SortTemp t = sort_temp_view(bin_view(binning_buffer, (size_t)R).sort_temp, 1, 0);
-        sort_err = t.err;
-        if (g_inject_sort_error.load(std::memory_order_relaxed) && hipMemsetAsync(t.err, 1, 1, st) != hipSuccess)
+        sort_err = sort_temp_view(bin_view(binning_buffer, (size_t)R).sort_temp, 1, 0).err;
+        depth_err = sort_temp_view(g.dsort_temp, 1, 0).err;
+        if (t_inject_sort_error &&
+            hipMemsetAsync((void*)(t_inject_sort_error == 2 ? depth_err : sort_err), 1, 1, st) != hipSuccess)
             return GSR_ERR_HIP;
     }
     if (s->P > 0) {
-        GSR_TRY(launch_finish_gstat(g, s->P, o->gauss_sum, o->gauss_count, sort_err, debug ? nullptr : o->sort_error_host, st));
+        GSR_TRY(launch_finish_gstat(g, s->P, o->gauss_sum, o->gauss_count, sort_err, depth_err,
+                                    debug ? nullptr : o->sort_error_host, st));
         mark(s, GSR_EV_FINISH, st);
     } else if (o->sort_error_host) {
         *o->sort_error_host = 0;  // nothing was sorted, nothing runs: the host word is set here
     }
     if (debug && sort_err) {
-        uint32_t err = 0;
-        if (hipMemcpyAsync(&err, sort_err, sizeof(err), hipMemcpyDeviceToHost, st) != hipSuccess) return GSR_ERR_HIP;
+        uint32_t err[2] = {0, 0};
+        if (hipMemcpyAsync(&err[0], sort_err, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return GSR_ERR_HIP;
+        if (hipMemcpyAsync(&err[1], depth_err, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return GSR_ERR_HIP;
         if (hipStreamSynchronize(st) != hipSuccess) return GSR_ERR_HIP;
-        if (err) return GSR_ERR_SORT;
+        if (err[0] | err[1]) return GSR_ERR_SORT;
     }
     if (debug && o->sort_error_host) *o->sort_error_host = 0;  // reported (or clean) through the return value
     return GSR_OK;
@@ -282,6 +291,9 @@ int gsr_backward_geometry_batch_range(const GsrScene* s, int nviews, const GsrBa
     if (!s || !io || nviews < 0 || (nviews > 0 && !views)) return GSR_ERR_ARG;
     if (s->P < 0) return GSR_ERR_ARG;
     if (first < 0 || count < 0 || (first % PRE_BLOCK) != 0 || (int64_t)first + count > s->P) return GSR_ERR_ARG;
+    // the block states (row_blocks, means2D_blocks) are kept per 64 rows: a range ends on a block boundary
+    // or at the last Gaussian, so that no call updates the state of a block it handled only part of
+    if ((count % 64) != 0 && (int64_t)first + count != s->P) return GSR_ERR_ARG;
     if (s->DIM != 0 && s->DIM != 4) return GSR_ERR_DIM;
     if (s->P == 0 || nviews == 0 || count == 0) return GSR_OK;
     if (!s->means3D || !s->opacities || !s->scales || !s->rotations || !s->shs || !s->shs_rest) return GSR_ERR_ARG;
@@ -398,11 +410,17 @@ int gsr_sort_pairs_u64_u32_noalloc(uint64_t* keys0, uint32_t* vals0, uint64_t* k
     if (n < 0 || end_bit < 0 || end_bit > 64 || !result_buffer) return GSR_ERR_ARG;
     *result_buffer = 0;
     if (n == 0 || end_bit == 0) return GSR_OK;
-    if (n > sort_static_max_pairs()) return GSR_ERR_LIMIT;
+    if (!sort_static_fits(n, 0, end_bit)) return GSR_ERR_LIMIT;
     if (!keys0 || !vals0 || !keys1 || !vals1) return GSR_ERR_ARG;
     uint64_t* k[2] = {keys0, keys1};
     uint32_t* v[2] = {vals0, vals1};
     return hip_status(launch_radix_sort_static(k, v, n, 0, end_bit, (hipStream_t)stream, result_buffer));
+}
+
+int gsr_sort_noalloc_error(void* stream, uint32_t* err) {
+    if (!err) return GSR_ERR_ARG;
+    *err = 0;
+    return hip_status(sort_static_read_error((hipStream_t)stream, err));
 }
 
 int gsr_layout(int P, int W, int H, int64_t R, GsrLayout* out) {
@@ -415,6 +433,7 @@ int gsr_layout(int P, int W, int H, int64_t R, GsrLayout* out) {
     out->clamped = (char*)g.clamped - z;
     out->block_sums = (char*)g.block_sums - z;
     out->total = (char*)g.total - z;
+    out->depth_sort = (char*)g.dsort_temp - z;
     const ImageView im = image_view(z, (size_t)W, (size_t)H);
     out->final_T = (char*)im.final_T - z;
     out->n_contrib = (char*)im.n_contrib - z;

@@ -746,14 +746,16 @@ __global__ void __launch_bounds__(256) keys64_kernel(const uint2* ranges, const 
         out[i] = ((uint64_t)tile << 32) | dt[point_list[i]].x;
 }
 
-// Also the last kernel of a forward pass: it hands the sort's error word to the caller's host word
-// (device-accessible pinned memory; a system-scope store, no copy engine, nothing for the stream to wait on).
+// Also the last kernel of a forward pass: it hands the sorts' error words (instance sort, depth order) to the
+// caller's host word (device-accessible pinned memory; a system-scope store, no copy engine, nothing for the
+// stream to wait on).
 __global__ void __launch_bounds__(256) finish_gstat_kernel(int P, const GStat* gstat, float* gauss_sum,
                                                            int* gauss_count, const uint32_t* sort_err,
-                                                           uint32_t* sort_err_host) {
+                                                           const uint32_t* depth_err, uint32_t* sort_err_host) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0 && sort_err_host)
-        __hip_atomic_store(sort_err_host, sort_err ? *sort_err : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(sort_err_host, (sort_err ? *sort_err : 0u) | (depth_err ? *depth_err : 0u), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
     if (i >= P) return;
     const GStat v = gstat[i];
     gauss_sum[i] = v.sum;
@@ -908,9 +910,9 @@ hipError_t launch_keys64(const GeomBuf& g, const uint2* ranges, int ntiles, cons
 }
 
 hipError_t launch_finish_gstat(const GeomBuf& g, int P, float* gauss_sum, int* gauss_count, const uint32_t* sort_err,
-                               uint32_t* sort_err_host, hipStream_t st) {
+                               const uint32_t* depth_err, uint32_t* sort_err_host, hipStream_t st) {
     hipLaunchKernelGGL(finish_gstat_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, g.gstat, gauss_sum,
-                       gauss_count, sort_err, sort_err_host);
+                       gauss_count, sort_err, depth_err, sort_err_host);
     return hipGetLastError();
 }
 

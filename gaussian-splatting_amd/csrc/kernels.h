@@ -93,10 +93,11 @@ hipError_t launch_tile_ranges(const uint32_t* keys, int64_t R, uint2* ranges, in
 // (tile << 32 | depth bits) of every sorted instance, as the reference's sort keys.
 hipError_t launch_keys64(const GeomBuf& g, const uint2* ranges, int ntiles, const uint32_t* point_list, int64_t R,
                          uint64_t* out, hipStream_t st);
-// Unpacks the statistics; as the last kernel of the forward it also stores *sort_err (0 if null) to
-// *sort_err_host (device-accessible host memory, may be null).
+// Unpacks the statistics; as the last kernel of the forward it also stores *sort_err | *depth_err (the error
+// words of the instance sort and of the depth order; 0 for a null pointer) to *sort_err_host
+// (device-accessible host memory, may be null).
 hipError_t launch_finish_gstat(const GeomBuf& g, int P, float* gauss_sum, int* gauss_count, const uint32_t* sort_err,
-                               uint32_t* sort_err_host, hipStream_t st);
+                               const uint32_t* depth_err, uint32_t* sort_err_host, hipStream_t st);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);
 
 // Returns the index (0/1) of the buffer pair that holds the sorted result.
@@ -105,6 +106,10 @@ hipError_t launch_radix_sort(uint64_t* keys[2], uint32_t* vals[2], int64_t n, in
 // The same sort with its temp area in a device array of the library (no caller buffer, no allocation);
 // n is limited to sort_static_max_pairs(); calls that overlap on one GPU race.
 int64_t sort_static_max_pairs();
+// Whether a sort of n pairs on these key bits fits the array (the 64-bit status words of the test hook need twice the room).
+bool sort_static_fits(int64_t n, int begin_bit, int end_bit);
+// Copies the error word the last such sort on the current device left (after everything enqueued on st) and waits.
+hipError_t sort_static_read_error(hipStream_t st, uint32_t* err);
 hipError_t launch_radix_sort_static(uint64_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit,
                                     hipStream_t st, int* result_buffer);
 // Zeroes the sort's status area and returns where its digit histograms go (for a caller that fills them itself).

@@ -34,10 +34,10 @@ template <class S> struct St {
 };
 
 namespace {
-std::atomic<int> g_force_wide{0};
+thread_local int t_force_wide = 0;   // test hook, per calling thread
 }
-bool sort_force_wide() { return g_force_wide.load(std::memory_order_relaxed) != 0; }
-void sort_set_force_wide(bool on) { g_force_wide.store(on ? 1 : 0, std::memory_order_relaxed); }
+bool sort_force_wide() { return t_force_wide != 0; }
+void sort_set_force_wide(bool on) { t_force_wide = on ? 1 : 0; }
 constexpr uint32_t SPIN_LIMIT = 1u << 22;
 #ifndef GS_LOOK_BATCH
 #define GS_LOOK_BATCH 4
@@ -1028,13 +1028,26 @@ hipError_t static_scratch(void** out) {
 
 int64_t sort_static_max_pairs() { return SORT_STATIC_MAX_PAIRS; }
 
+bool sort_static_fits(int64_t n, int begin_bit, int end_bit) {
+    if (n <= 0 || end_bit <= begin_bit) return true;
+    return n <= SORT_STATIC_MAX_PAIRS &&
+           sort_temp_view(nullptr, (size_t)n, sort_passes_for(begin_bit, end_bit)).bytes <= SORT_STATIC_BYTES;
+}
+
+hipError_t sort_static_read_error(hipStream_t st, uint32_t* err) {
+    void* temp = nullptr;
+    hipError_t e = static_scratch(&temp);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(err, sort_temp_view(temp, 1, 0).err, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(st);
+}
+
 hipError_t launch_radix_sort_static(uint64_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit,
                                     hipStream_t st, int* result_buffer) {
     *result_buffer = 0;
     if (n <= 0 || end_bit <= begin_bit) return hipSuccess;
-    if (n > SORT_STATIC_MAX_PAIRS ||
-        sort_temp_view(nullptr, (size_t)n, sort_passes_for(begin_bit, end_bit)).bytes > SORT_STATIC_BYTES)
-        return hipErrorInvalidValue;
+    if (!sort_static_fits(n, begin_bit, end_bit)) return hipErrorInvalidValue;
     void* temp = nullptr;
     hipError_t e = static_scratch(&temp);
     if (e != hipSuccess) return e;

@@ -10,8 +10,6 @@
 // reduced over the wave 16 instances at a time by a transposing reduction,
 // over the four waves through LDS, and leave the workgroup as one pair of
 // adjacent float atomics per instance.
-#include <atomic>
-
 #include "kernels.h"
 
 namespace gs {
@@ -248,8 +246,8 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
     }
 }
 
-static std::atomic<int> g_reach_masks{-1};
-void render_fwd_set_reach_masks(int mode) { g_reach_masks.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
+static thread_local int t_reach_masks = -1;   // test hook, per calling thread
+void render_fwd_set_reach_masks(int mode) { t_reach_masks = mode < 0 ? -1 : (mode ? 1 : 0); }
 
 hipError_t launch_render_fwd(const GsrScene& s, const GsrForwardOut& o, const GeomBuf& g, const ImageView& im,
                              const uint32_t* point_list, int64_t num_rendered, int64_t num_visible, hipStream_t st) {
@@ -274,7 +272,7 @@ hipError_t launch_render_fwd(const GsrScene& s, const GsrForwardOut& o, const Ge
     const bool invd = o.out_invdepth != nullptr;
     // small splats (fewer than six tiles per rendered Gaussian on average): the quadrant reach masks pay
     const int64_t nvis = num_visible > 0 ? num_visible : s.P;
-    const int forced = g_reach_masks.load(std::memory_order_relaxed);
+    const int forced = t_reach_masks;
     const bool reach = forced < 0 ? num_rendered < 6 * nvis : forced != 0;
 #define GS_LAUNCH_FWD(D, I, R) hipLaunchKernelGGL((render_fwd_kernel<D, I, R>), grid, block, 0, st, a)
     if (s.DIM == 4) {

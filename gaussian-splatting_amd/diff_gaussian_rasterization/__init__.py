@@ -12,10 +12,20 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if _PKG_ROOT not in sys.path:
     sys.path.insert(0, _PKG_ROOT)
 
+import warnings
+
 import torch
 import torch.nn as nn
 
 from . import _C
+
+_warned = set()
+
+
+def _warn_once(key, message):
+    if key not in _warned:
+        _warned.add(key)
+        warnings.warn(message, RuntimeWarning, stacklevel=3)
 
 
 def cpu_deep_copy_tuple(input_tuple):
@@ -158,6 +168,10 @@ class ParamGradSink:
         self.fresh = True
         self.defer = bool(defer) and "sh_rest" in self.grads and \
             features_dc.size(1) + features_rest.size(1) == 16
+        if defer and not self.defer:
+            _warn_once("defer", "ParamGradSink(defer=True): the batched per-Gaussian backward needs split SH tensors "
+                       "with 16 coefficients in all (SH degree 3 allocated); this model has not, so every view's "
+                       "backward runs the one-view kernel (same gradients, slower)")
         self.pending = []
         self.prepared = []
         self.hit_counts = []
@@ -219,7 +233,12 @@ class ParamGradSink:
         while the parameters keep their values (`begin_step()` drops what was not used).
         Needs 16 SH coefficients; otherwise does nothing."""
         p = self.params
-        if not settings_list or "sh_rest" not in self.grads or p["sh"].size(1) + p["sh_rest"].size(1) != 16:
+        if not settings_list:
+            return
+        if "sh_rest" not in self.grads or p["sh"].size(1) + p["sh_rest"].size(1) != 16:
+            _warn_once("prepare", "ParamGradSink.prepare_views: the batched forward preprocess needs split SH tensors "
+                       "with 16 coefficients in all (SH degree 3 allocated); this model has not, so every view runs "
+                       "its own preprocess (same results, slower)")
             return
         groups = {}   # one call per (scale modifier, degree): the rest is per view
         for rs in settings_list:

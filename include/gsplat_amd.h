@@ -139,7 +139,8 @@ typedef struct {
                                 num_visible): the geometry buffer also holds the view's front-to-back order of
                                 the Gaussians, and gsr_forward_stage2 does not sort them again */
     uint32_t* sort_error_host; /* NULL, or a word of host memory that the GPU can write (hipHostMalloc / pinned):
-                                the last kernel of gsr_forward_stage2 stores the radix sort's error word there, in
+                                the last kernel of gsr_forward_stage2 stores the radix sorts' error words there (the
+                                instance sort's OR the depth order's, also when gsr_preprocess_batch made that order), in
                                 stream order and without making the call wait.  Nonzero = a look-back did not
                                 complete within its spin limit and the instance list is not valid (what
                                 GSR_ERR_SORT reports when scene->debug makes the call wait; then 0 is stored).
@@ -230,8 +231,9 @@ int gsr_backward_blend(const GsrScene* scene, const int* radii, const void* geom
                        const void* image_buffer, int64_t num_rendered, const GsrBackwardIO* io, void* stream);
 int gsr_backward_geometry_batch(const GsrScene* scene, int nviews, const GsrBackwardView* views,
                                 const GsrBackwardIO* io, void* stream);
-/* The same for the Gaussians [first, first + count) only (first a multiple of 256, first + count <= P):
- * rows of the gradient tensors outside the range are not touched.  A caller that exchanges the
+/* The same for the Gaussians [first, first + count) only (first a multiple of 256, first + count <= P,
+ * count a multiple of 64 unless the range ends at P: the block states are kept per 64 rows; otherwise
+ * GSR_ERR_ARG): rows of the gradient tensors outside the range are not touched.  A caller that exchanges the
  * gradients between GPUs runs the ranges one after the other and starts the exchange of a range's
  * rows as soon as its call is enqueued, so that the exchange overlaps the remaining ranges. */
 int gsr_backward_geometry_batch_range(const GsrScene* scene, int nviews, const GsrBackwardView* views,
@@ -247,7 +249,8 @@ int gsr_backward_geometry_batch_range(const GsrScene* scene, int nviews, const G
  * straight to gsr_forward_stage2 (GsrForwardOut.preprocessed = 1, or 2 where depth_ordered was reported,
  * num_visible copied over, the same three buffers), so a step of V views blocks the host once instead of
  * V times.
- * (gsr_forward_stage1 with preprocessed = 1 is also allowed: it repeats the sums and the copy.)
+ * (gsr_forward_stage1 with preprocessed != 0 is also allowed: the sums are in place, so it only repeats the
+ * copy of the view's totals and returns the same two counts.)
  * Needs the SH tensors split (scene->shs_rest), M == 16 and scales + rotations; the camera fields,
  * W, H and antialiasing of `scene` are ignored (each view brings its own).  Returns
  * GSR_ERR_OVERFLOW if a view has more than 2^31 - 1 instances. */
@@ -284,21 +287,32 @@ size_t gsr_sort_temp_error_offset(void);
 int gsr_sort_pairs_u64_u32(uint64_t* keys0, uint32_t* vals0, uint64_t* keys1, uint32_t* vals1, int64_t n, int end_bit,
                            void* temp, size_t temp_bytes, void* stream, int* result_buffer);
 
-/* The same sort for callers that cannot allocate device memory or bring a temp buffer (code under HIP
- * graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
- * reference.  The sort's temp area (digit histograms, tickets, look-back status words) is a device
- * array inside the library, 4 MiB per GPU that the library runs on, held until the process ends;
- * the call allocates and frees nothing.  n is limited to gsr_sort_noalloc_max_pairs() (2^21 pairs);
- * more returns GSR_ERR_LIMIT.  Every call on a GPU uses that GPU's one array: calls that overlap on
- * one GPU (two streams, two threads) race; calls on one stream, or otherwise ordered, are fine.
- * Results are bit-identical to gsr_sort_pairs_u64_u32. */
+/* The same sort for callers that cannot allocate device memory or bring a temp buffer (tight serving
+ * loops, harnesses that forbid hipMalloc, code that will later run under HIP graph capture).  No
+ * counterpart in the reference.  The sort's temp area (digit histograms, tickets, look-back status
+ * words) is a device array inside the library, 4 MiB per GPU that the library runs on, held until the
+ * process ends; the call allocates and frees nothing.  It is not free of other runtime calls: the
+ * first call on a device looks the array's address up (hipGetSymbolAddress) and every call sets a
+ * kernel attribute (hipFuncSetAttribute) before its launches and clears its temp area with
+ * hipMemsetAsync; a caller that captures it into a graph makes one call outside the capture first
+ * (capture itself is not covered by this library's tests).  n is limited to
+ * gsr_sort_noalloc_max_pairs() (2^21 pairs); more, or a sort whose status words do not fit the array
+ * (gsr_test_force_wide_sort_status doubles them), returns GSR_ERR_LIMIT.  Every call on a GPU uses
+ * that GPU's one array: calls that overlap on one GPU (two streams, two threads) race and nothing
+ * detects it; calls on one stream, or otherwise ordered, are fine.  Results are bit-identical to
+ * gsr_sort_pairs_u64_u32.
+ * gsr_sort_noalloc_error: the error word of the last such sort on the current device (nonzero = a
+ * look-back did not complete, the output is not valid); waits for `stream`. */
 int64_t gsr_sort_noalloc_max_pairs(void);
 int gsr_sort_pairs_u64_u32_noalloc(uint64_t* keys0, uint32_t* vals0, uint64_t* keys1, uint32_t* vals1, int64_t n,
                                    int end_bit, void* stream, int* result_buffer);
+int gsr_sort_noalloc_error(void* stream, uint32_t* err);
 
 /* Debug / test access: byte offsets of the arrays inside the scratch buffers. */
 typedef struct {
     size_t rec, cov3D, tiles, clamped, block_sums, total;           /* geometry buffer */
+    size_t depth_sort;                                               /* geometry buffer: temp area of the depth order's
+                                                                        sort (its error word: + gsr_sort_temp_error_offset()) */
     size_t final_T, n_contrib, ranges;                               /* image buffer */
     size_t keys0, keys1, vals0, vals1;                               /* binning buffer: u32 tile ids, u32 indices */
     int sorted_buffer;                                               /* which pair holds the sorted list; its vals
@@ -424,7 +438,9 @@ int gso_compact_map(int64_t N, const uint8_t* keep, uint32_t* src_of_dst, void* 
                     void* stream);
 int gso_gather_rows(const void* src, void* dst, const uint32_t* src_of_dst, int64_t K, int M, void* stream);
 
-/* Test hook: while on, the radix sorts use the 64-bit look-back status words of sorts of 2^30 pairs and more
+/* The four test hooks below are per calling thread: they change the calls made from the thread that set
+ * them and nothing else.
+ * Test hook: while on, the radix sorts use the 64-bit look-back status words of sorts of 2^30 pairs and more
  * at any size (gsr_sort_temp_bytes and gsr_binning_bytes answer accordingly). */
 void gsr_test_force_wide_sort_status(int on);
 
@@ -439,8 +455,9 @@ void gsr_test_forward_reach_masks(int mode);
  * at 1080p, 2^24 at 4K); the sorted tile ids are then not stored.  Off: always as a (tile id, index) pair. */
 void gsr_test_packed_instances(int on);
 
-/* Test hook: while on, every gsr_forward_stage2 sets its sort's error word as a tripped look-back would. */
-void gsr_test_inject_sort_error(int on);
+/* Test hook: while set, every gsr_forward_stage2 sets a sort's error word as a tripped look-back would:
+ * 1 the instance sort's (binning buffer), 2 the depth order's (geometry buffer); 0 off. */
+void gsr_test_inject_sort_error(int which);
 
 const char* gsr_status_string(int status);
 

@@ -182,10 +182,12 @@ def test_many_one_tile_gaussians_per_emission_chunk(oracle):
     assert f.R < 2 * (f.radii > 0).sum()
 
 
-def test_sort_error_word_is_surfaced_without_debug():
-    """A look-back that trips its spin limit leaves an error word on the device.  With debug the forward
-    call waits and fails; without it the call returns (it must not wait), and the next call into the
-    rasterizer after the GPU has passed that point raises.  The error is injected through the test hook."""
+@pytest.mark.parametrize("which", [1, 2], ids=["instance_sort", "depth_order"])
+def test_sort_error_word_is_surfaced_without_debug(which):
+    """A look-back that trips its spin limit leaves an error word on the device: the instance sort's in the
+    binning buffer, the depth order's in the geometry buffer.  With debug the forward call waits and fails;
+    without it the call returns (it must not wait), and the next call into the rasterizer after the GPU has
+    passed that point raises.  The error is injected through the test hook, into either word."""
     import synth
     from _gsplat_lib import lib, sort_errors
     from gpu_util import run_forward_raw, scene_to_torch
@@ -193,7 +195,7 @@ def test_sort_error_word_is_surfaced_without_debug():
     sc = synth.tiny_scene(P=300, width=64, height=48, seed=3)
     sort_errors.poll(block=True)
     try:
-        L.gsr_test_inject_sort_error(1)
+        L.gsr_test_inject_sort_error(which)
         rs, ten = scene_to_torch(sc, debug=True)
         with pytest.raises(RuntimeError, match="look-back"):
             run_forward_raw(rs, ten)
@@ -201,7 +203,7 @@ def test_sort_error_word_is_surfaced_without_debug():
     finally:
         L.gsr_test_inject_sort_error(0)
     try:
-        L.gsr_test_inject_sort_error(1)
+        L.gsr_test_inject_sort_error(which)
         rs, ten = scene_to_torch(sc, debug=False)
         out = run_forward_raw(rs, ten)        # returns: the host does not wait for the word
         assert out["num_rendered"] > 0
@@ -212,6 +214,53 @@ def test_sort_error_word_is_surfaced_without_debug():
         run_forward_raw(rs, ten)              # the next call finds the word of the one before
     out = run_forward_raw(rs, ten)            # and the state is clean again
     torch.cuda.synchronize()
+    sort_errors.poll(block=True)
+
+
+def test_depth_order_error_of_the_batch_call_reaches_the_views_host_word():
+    """gsr_preprocess_batch makes the front-to-back orders of all the views of a step; a tripped look-back
+    there sets the error word in that view's geometry buffer, and the view's gsr_forward_stage2 hands it to
+    the host word together with its own sort's.  The word is set by hand behind the batch call."""
+    import ctypes as C
+    import synth
+    from _gsplat_lib import lib, sort_errors
+    from diff_gaussian_rasterization import _C as host
+    from test_gpu_params_mode import _arc_settings, _raw_scene
+    L = lib()
+    W, H, P = 96, 64, 400
+    sc = synth.tiny_scene(P=P, width=W, height=H, seed=31)
+    raw = _raw_scene(sc, seed=5)
+    settings = _arc_settings(2, W, H, debug=False)
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda:0")
+    ten = dict(xyz=t(sc["means3D"]), dc=t(raw["features_dc"]), rest=t(raw["features_rest"]), opacity=t(raw["opacity"]),
+               scaling=t(raw["scaling"]), rotation=t(raw["rotation"]), reps=t(sc["reps"]))
+    e = torch.Tensor([])
+    sort_errors.poll(block=True)
+    prep = host.preprocess_batch(ten["xyz"], ten["opacity"], ten["scaling"], ten["rotation"], 1.0, ten["dc"], ten["rest"],
+                                 3, ten["reps"], True, settings, debug=False)
+    assert prep[1]["depth_ordered"] and prep[1]["num_rendered"] > 0
+    # where the depth order's error word lives: the sort area is the last array of the geometry buffer
+    geom = prep[1]["geom"]
+    from _gsplat_lib import GsrLayout
+    lay = GsrLayout()
+    assert L.gsr_layout(P, W, H, prep[1]["num_rendered"], C.byref(lay)) == 0
+    off = lay.depth_sort + L.gsr_sort_temp_error_offset()
+    assert int(geom[off:off + 4].view(torch.int32).item()) == 0
+    geom[off:off + 4].view(torch.int32).fill_(1)
+
+    def fwd(rs, pr):
+        return host.rasterize_gaussians(
+            rs.bg, ten["xyz"], e, ten["opacity"], ten["scaling"], ten["rotation"], rs.scale_modifier, e, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, ten["dc"], rs.sh_degree, rs.campos,
+            False, rs.antialiasing, rs.debug, ten["reps"], sh_rest=ten["rest"], raw_params=True, prepared=pr)
+
+    fwd(settings[0], prep[0])                  # the other view is clean
+    torch.cuda.synchronize()
+    sort_errors.poll(block=True)
+    fwd(settings[1], prep[1])                  # returns; the word arrives behind it
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="look-back"):
+        sort_errors.poll(block=True)
     sort_errors.poll(block=True)
 
 

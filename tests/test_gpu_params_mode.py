@@ -347,6 +347,37 @@ def test_batched_forward_preprocess_is_bit_identical(nviews, P):
         for k in ("keys", "point_list", "n_contrib", "ranges", "final_T"):
             assert np.array_equal(ia[k], ib[k]), k
     assert seen_any > 0
+    # gsr_forward_stage1 behind the batch call (allowed: the sums are in place, it only fetches the totals
+    # again): the same counts, and the view renders the same image from the same order
+    # (a prepared view serves one forward: the hit counts accumulate in its geometry buffer)
+    prep2 = _C.preprocess_batch(ten["xyz"], ten["opacity"], ten["scaling"], ten["rotation"], 1.0, ten["dc"], ten["rest"], 3,
+                                ten["reps"], True, settings, debug=True)
+    rs, pr = settings[0], dict(prep2[0])
+    ref = fwd(rs, None)
+    R, nvis = pr.pop("num_rendered"), pr.pop("num_visible")
+    c = fwd(rs, pr)                      # without the counts the host layer asks stage 1 for them
+    torch.cuda.synchronize()
+    assert c["num_rendered"] == R == ref["num_rendered"]
+    assert torch.equal(c["color"], ref["color"]) and torch.equal(c["gauss_count"], ref["gauss_count"])
+    assert np.array_equal(read_internals(c, P, W, H)["point_list"], read_internals(ref, P, W, H)["point_list"])
+
+
+def test_declined_batch_path_warns_once():
+    """A model without 16 SH coefficients cannot take the batched kernels; the sink says so once."""
+    import warnings
+    import diff_gaussian_rasterization as dgr
+    P = 64
+    z = lambda *sh: torch.zeros(sh, device="cuda:0", requires_grad=True)
+    dgr._warned.clear()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        sink = dgr.ParamGradSink(z(P, 3), z(P, 1, 3), z(P, 8, 3), z(P, 1), z(P, 3), z(P, 4), z(P, 4), defer=True)
+        assert not sink.defer
+        dgr.ParamGradSink(z(P, 3), z(P, 1, 3), z(P, 8, 3), z(P, 1), z(P, 3), z(P, 4), z(P, 4), defer=True)
+        sink.prepare_views(_arc_settings(2, 32, 32))
+        sink.prepare_views(_arc_settings(2, 32, 32))
+    msgs = [str(x.message) for x in w if issubclass(x.category, RuntimeWarning)]
+    assert len(msgs) == 2 and "16 coefficients" in msgs[0] and "prepare_views" in msgs[1]
 
 
 @pytest.mark.parametrize("defer", [False, True], ids=["per_view_backward", "deferred_backward"])

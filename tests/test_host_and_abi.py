@@ -113,6 +113,26 @@ def test_argument_validation_without_gpu():
     assert L.gso_gather_rows(None, None, None, 5, 0, None) == -1
 
 
+def test_batched_backward_range_must_cover_whole_blocks():
+    """The block states of the batched per-Gaussian backward are kept per 64 rows: a range that ends inside a
+    block (and not at the last Gaussian) is refused instead of leaving a half-handled block's state behind."""
+    import ctypes as C
+    from _gsplat_lib import GsrBackwardIO, GsrBackwardView, GsrScene, lib
+    L = lib()
+    s = GsrScene()
+    s.P, s.W, s.H, s.M, s.D = 1000, 64, 64, 16, 3
+    bv = (GsrBackwardView * 1)()
+    io = GsrBackwardIO()
+    # argument checks come before anything is dereferenced: -1 for the range, and the same call with a
+    # whole-block range gets past the range check (and then fails on the null parameters, also -1, so the
+    # two are told apart by a range that is refused although every pointer check would pass: count 0)
+    assert L.gsr_backward_geometry_batch_range(C.byref(s), 0, bv, C.byref(io), 0, 100, None) == -1
+    assert L.gsr_backward_geometry_batch_range(C.byref(s), 0, bv, C.byref(io), 0, 128, None) == 0
+    assert L.gsr_backward_geometry_batch_range(C.byref(s), 0, bv, C.byref(io), 768, 232, None) == 0   # ends at P
+    assert L.gsr_backward_geometry_batch_range(C.byref(s), 0, bv, C.byref(io), 768, 200, None) == -1
+    assert L.gsr_backward_geometry_batch_range(C.byref(s), 0, bv, C.byref(io), 100, 128, None) == -1  # first % 256
+
+
 def test_operator_layer_mirrors_reference_checks():
     import diff_gaussian_rasterization as dgr
     assert dgr.GaussianRasterizationSettings._fields == (

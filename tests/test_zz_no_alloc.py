@@ -53,6 +53,8 @@ def test_noalloc_sort_matches_the_sort_with_a_temp_buffer():
         assert got[2] == ref[2]
         assert np.array_equal(got[0], ref[0])
         assert np.array_equal(got[1], ref[1])
+        err = C.c_uint32(7)     # the error word of the sort just made, from the library's own array
+        assert L.gsr_sort_noalloc_error(torch.cuda.current_stream().cuda_stream, C.byref(err)) == 0 and err.value == 0
 
 
 def test_noalloc_sort_rejects_what_does_not_fit():
@@ -66,3 +68,13 @@ def test_noalloc_sort_rejects_what_does_not_fit():
     assert rc == -7
     assert b"scratch" in L.gsr_status_string(rc)
     assert L.gsr_sort_pairs_u64_u32_noalloc(None, None, None, None, 0, 44, None, C.byref(res)) == 0
+    # 64-bit status words (test hook) take twice the room: the largest size then no longer fits the array,
+    # and that is a limit, not a runtime error
+    try:
+        L.gsr_test_force_wide_sort_status(1)
+        rc = L.gsr_sort_pairs_u64_u32_noalloc(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), nmax, 64, None,
+                                              C.byref(res))
+    finally:
+        L.gsr_test_force_wide_sort_status(0)
+    assert rc == -7
+    assert L.gsr_sort_noalloc_error(None, None) == -1
