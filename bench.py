@@ -289,6 +289,21 @@ def pmc_file(scene):
     return os.path.join(ROOT, "profiles", "pmc_traffic.json" if scene == "street" else f"pmc_traffic_{scene}.json")
 
 
+def pmc_is_stale(P, W, H, scene="street"):
+    """True when the committed counter summary was collected on a library built from other sources than
+    the ones at hand (or says nothing about its build): its instruction counts and traffic then describe
+    other kernels, and no roofline fraction is derived from them."""
+    try:
+        from _gsplat_lib import source_hash
+        with open(pmc_file(scene)) as f:
+            d = json.load(f)
+        if d.get("_workload") != [P, W, H]:
+            return False          # no summary for this workload: nothing is used
+        return d.get("_build") != source_hash()
+    except Exception:
+        return False
+
+
 def load_pmc_valu(P, W, H, scene="street"):
     """Per kernel: wave64 vector instructions per launch, LDS atomics per launch and the shader clock, from
     the committed PMC summary of this command (empty if none matches the workload)."""
@@ -458,6 +473,7 @@ def main():
 
     reducer = gsdp.GradReducer(sparse={"auto": "auto", "dense": "never", "sparse": "always"}[args.reduce])
     reduce_modes = []
+    exchange = {"reducer": reducer, "ms": reducer_ms, "modes": reduce_modes}   # what step() exchanges through
 
     def step(k=None, timer=None, overlap=True):
         # the views are dealt to the current stream and the side streams in turn (only when the per-Gaussian
@@ -506,16 +522,16 @@ def main():
             # RCCL (its own stream) as soon as the launch is enqueued and are exchanged while the later ranges
             # are computed.  e1: the compute stream's own work of the step ends, from there it waits for the
             # exchange.
-            mode = gsdp.reduce_flush(sink, reducer, chunks=args.reduce_chunks, after_flush=e1.record)
+            mode = gsdp.reduce_flush(sink, exchange["reducer"], chunks=args.reduce_chunks, after_flush=e1.record)
         else:
-            reducer.start([p.grad for p in leaves])
+            exchange["reducer"].start([p.grad for p in leaves])
             e1.record()
-            reducer.wait()
+            exchange["reducer"].wait()
             mode = "dense"
         e2.record()
         if k is not None:
-            reducer_ms.append((e0, e1, e2))
-            reduce_modes.append(mode)
+            exchange["ms"].append((e0, e1, e2))
+            exchange["modes"].append(mode)
         return out
 
     def sync():
@@ -550,6 +566,33 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # The same step with every gradient row exchanged ("dense"), when the timed region did not already: on a
+    # scene whose views reach few Gaussians the default policy exchanges a few MB, and the scaling that shows
+    # says nothing about a model whose every Gaussian is seen.  A few steps, timed the same way (barrier +
+    # synchronize on both sides, max over the ranks).
+    dense_leg = None
+    if world > 1 and not args.fwd_only and use_params and args.reduce != "dense":
+        dense_steps = max(2, min(args.steps, 6))
+        exchange.update(reducer=gsdp.GradReducer(sparse="never"), ms=[], modes=[])
+        step(0, None)
+        exchange["ms"].clear()
+        exchange["modes"].clear()
+        sync()
+        t1 = time.perf_counter()
+        for k in range(dense_steps):
+            step(k, None)
+        sync()
+        ddt = time.perf_counter() - t1
+        tmax = torch.tensor([ddt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ddt = float(tmax.item())
+        dense_leg = {"steps": dense_steps, "ms_per_step": ddt / dense_steps * 1e3,
+                     "it_s": world * V * dense_steps / ddt,
+                     "flush_ms": float(np.mean([a.elapsed_time(b) for a, b, _ in exchange["ms"]])),
+                     "exposed_ms": float(np.mean([b.elapsed_time(c) for _, b, c in exchange["ms"]])),
+                     "steps_dense": exchange["modes"].count("dense")}
+        exchange.update(reducer=reducer, ms=reducer_ms, modes=reduce_modes)
+
     # one all-reduce of the whole gradient buffer on its own (every rank takes part)
     allreduce_alone_ms = None
     if world > 1 and not args.fwd_only:
@@ -563,6 +606,13 @@ def main():
             torch.cuda.synchronize()
             ts.append((time.perf_counter() - t1) * 1e3)
         allreduce_alone_ms = float(np.mean(ts[1:]))
+
+    collective_version = None
+    if world > 1 and backend == "nccl":
+        try:
+            collective_version = "RCCL (torch.cuda.nccl.version) " + ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as ex:
+            collective_version = "unknown: " + repr(ex)
 
     deferred = use_params and sink.defer and not args.fwd_only
 
@@ -584,6 +634,7 @@ def main():
         kernels_overlapped = kernel_means(timer, args.steps)
         iso_steps = min(args.steps, 5)
         timer = KernelTimer(iso_steps * V)
+        exchange.update(ms=[], modes=[])      # the exchange figures are those of the timed region only
         step(0, timer, overlap=False)
         sync()
         t1 = time.perf_counter()
@@ -591,6 +642,7 @@ def main():
             step(k, timer, overlap=False)
         sync()
         one_stream_it_s = world * V * iso_steps / (time.perf_counter() - t1)
+        exchange.update(ms=reducer_ms, modes=reduce_modes)
         timer.arm(None)
         kernels = kernel_means(timer, iso_steps)
     else:
@@ -769,7 +821,8 @@ def main():
             extras["translucent"] = {"error": repr(ex)}
 
     if rank == 0:
-        traffic = load_pmc_traffic(P, W, H, args.scene)
+        pmc_stale = pmc_is_stale(P, W, H, args.scene)
+        traffic = {} if pmc_stale else load_pmc_traffic(P, W, H, args.scene)
         per_kernel = {}
         launches = lambda k: 1 if k in KernelTimer.PER_STEP else V          # per step
 
@@ -798,7 +851,7 @@ def main():
         # Vector-instruction issue: wave64 instructions a launch executes (SQ_INSTS_VALU of the committed PMC passes
         # of this command) over the live duration, against 1024 SIMDs x 0.5 instructions per clock (a wave64
         # instruction issues over 2 cycles on a 32-lane SIMD) at the clock the counters show.
-        valu = load_pmc_valu(P, W, H, args.scene)
+        valu = {} if pmc_stale else load_pmc_valu(P, W, H, args.scene)
         for k, ent in per_kernel.items():
             if k in valu:
                 v = valu[k]
@@ -857,6 +910,13 @@ def main():
                                                 packed=packed) /
                               (kernels["sort"] * 1e-3) / 1e9) if R else None,
         }
+        if pmc_stale:
+            # the counter summary under profiles/ belongs to another build of the kernels: nothing is derived from it
+            res["pmc_stale"] = True
+            if BOUND.get(dom, "hbm").startswith("valu"):
+                res["roofline"]["frac"] = None
+                res["roofline"]["note"] = ("vector-issue fraction withheld: profiles/pmc_traffic*.json was collected "
+                                           "on other kernel sources (re-run tools/collect_pmc.sh and tools/pmc_summary.py)")
         if overlapping:
             res["kernels_in_timed_region_ms"] = kernels_overlapped
             res["one_stream_it_s"] = one_stream_it_s
@@ -884,7 +944,11 @@ def main():
                 "steps_dense": reduce_modes.count("dense"), "steps_sparse": reduce_modes.count("sparse"),
                 "union_rows": reducer.last_union[0] if reducer.last_union else None,
                 "union_fraction": (reducer.last_union[0] / max(1, reducer.last_union[1])) if reducer.last_union else None,
-                "bytes_sparse": (reducer.last_union[0] * (nbytes // max(1, P)) + P) if reducer.last_union else None}
+                "bytes_sparse": (reducer.last_union[0] * (nbytes // max(1, P)) + P) if reducer.last_union else None,
+                # the same step with every row exchanged (a model whose every Gaussian some view sees): THE number
+                # to read multi-GPU scaling from when `policy` let the timed steps go sparse
+                "dense": dense_leg,
+                "ranks_seen": dist.get_world_size(), "backend": backend, "collective_library": collective_version}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(P, W, H, seed, args.scene == "translucent")

@@ -290,3 +290,21 @@ def dev_f32(t, device, what):
     if t.dtype != torch.float32:
         raise RuntimeError(f"{what} must be float32, got {t.dtype}")
     return t.contiguous()
+
+
+def source_hash():
+    """Hash of everything libgsplat_amd.so is built from (kernel sources, headers, Makefile).  Profiles
+    and counter summaries collected on one build carry it, so that a reader can tell whether they still
+    describe the sources at hand."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h")) +
+                   [os.path.join(here, "csrc", "Makefile"),
+                    os.path.join(os.path.dirname(here), "include", "gsplat_amd.h")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

@@ -128,6 +128,10 @@ def main():
     # bench.py defaults, which tools/collect_pmc.sh runs; another scene's file is never bench.py's default one
     out_d["_workload"] = [6000000, 1920, 1080]
     out_d["_scene"] = "street" if traffic_json == "pmc_traffic.json" else traffic_json[len("pmc_traffic_"):-len(".json")]
+    # the sources the profiled library was built from: bench.py compares this with the sources it runs on
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting_amd"))
+    from _gsplat_lib import source_hash
+    out_d["_build"] = source_hash()
     out_d["_note"] = "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB, mean over the launches of the PMC passes"
     with open(os.path.join(ROOT, "profiles", traffic_json), "w") as f:
         json.dump(out_d, f, indent=1)
