@@ -41,6 +41,7 @@ struct PreBwdArgs {
     const GStat* gstat;   // the forward's per-Gaussian (sum of T, pixels that reached it)
     const uint8_t* clamped;
     const GradRec* acc;
+    const float4* accx;   // [P][4] float4: sums of the feature channels 4 .. DIM - 1 (DIM > 4), else unused
     int has_invdepth;
     float* dL_dmeans2D;
     float* dL_dcolors;
@@ -55,6 +56,24 @@ struct PreBwdArgs {
     uint8_t* row_blocks;  // batch kernel only, may be null: see GsrBackwardIO.row_blocks
 };
 
+
+// dL/dreps row of Gaussian i (DIM = 4, 8 or 16 floats): channels 0 .. 3 from the GradRec (`lo`), the others
+// from the second record (x[0 .. DIM / 4 - 2]).
+// (a fixed trip count with guards: `x` may be an array in registers, which must not be indexed dynamically)
+__device__ __forceinline__ void reps_row_out(float* dL_dreps, size_t i, int DIM, bool accum, float4 lo, const float4* x) {
+    float4* p = reinterpret_cast<float4*>(dL_dreps + i * (size_t)DIM);
+#pragma unroll
+    for (int e = 0; e < REPS_MAX / 4; ++e) {
+        if (4 * e >= DIM) break;
+        const float4 v = e == 0 ? lo : x[e - 1];
+        if (accum) {
+            const float4 o = p[e];
+            p[e] = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+        } else {
+            p[e] = v;
+        }
+    }
+}
 
 // Everything for one rendered Gaussian.
 template <int MODE>
@@ -210,18 +229,14 @@ __device__ __forceinline__ void pre_bwd_rendered(const PreBwdArgs& a, size_t i, 
         a.dL_dmeans3D[3 * i] += dmean.x;
         a.dL_dmeans3D[3 * i + 1] += dmean.y;
         a.dL_dmeans3D[3 * i + 2] += dmean.z;
-        if (a.DIM == 4) {
-            float4* p = reinterpret_cast<float4*>(a.dL_dreps) + i;
-            const float4 o = *p;
-            *p = make_float4(o.x + g2.z, o.y + g2.w, o.z + g3.x, o.w + g3.y);
-        }
     } else {
         a.dL_dopacity[i] = dop;
         a.dL_dmeans3D[3 * i] = dmean.x;
         a.dL_dmeans3D[3 * i + 1] = dmean.y;
         a.dL_dmeans3D[3 * i + 2] = dmean.z;
-        if (a.DIM == 4) reinterpret_cast<float4*>(a.dL_dreps)[i] = make_float4(g2.z, g2.w, g3.x, g3.y);
     }
+    if (a.DIM >= 4)
+        reps_row_out(a.dL_dreps, i, a.DIM, accum, make_float4(g2.z, g2.w, g3.x, g3.y), a.accx + 4 * i);
 }
 
 // A Gaussian the forward did not render: every gradient is zero.
@@ -260,7 +275,8 @@ __device__ __forceinline__ void pre_bwd_unrendered(const PreBwdArgs& a, size_t i
         a.dL_dscales[3 * i] = a.dL_dscales[3 * i + 1] = a.dL_dscales[3 * i + 2] = 0.f;
         reinterpret_cast<float4*>(a.dL_drotations)[i] = make_float4(0, 0, 0, 0);
     }
-    if (a.DIM == 4) reinterpret_cast<float4*>(a.dL_dreps)[i] = make_float4(0, 0, 0, 0);
+    for (int e = 0; e < a.DIM / 4; ++e)
+        reinterpret_cast<float4*>(a.dL_dreps + i * (size_t)a.DIM)[e] = make_float4(0, 0, 0, 0);
 }
 
 #ifndef PRE_BWD_WAVES
@@ -329,6 +345,7 @@ struct BatchView {
     const GStat* gstat;
     const uint8_t* clamped;
     const GradRec* acc;
+    const float4* accx;  // that view's second records (feature channels 4 .. DIM - 1), DIM > 4
     float* dL_dmeans2D;  // [P,3] of this view, or null
     uint8_t* m2_blocks;  // may be null: see GsrBackwardView.means2D_blocks
 };
@@ -343,6 +360,8 @@ struct PreBwdBatchArgs {
 #ifndef PRE_BWD_BATCH_WAVES
 #define PRE_BWD_BATCH_WAVES 2
 #endif
+// WIDE: more than four feature channels (their sums come from every view's second record).
+template <bool WIDE>
 __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch_kernel(const PreBwdBatchArgs b) {
     constexpr int WAVE_LDS = ShLds<SH_SPLIT16>::bytes_per_wave;
     __shared__ __align__(16) char s_sh[4 * WAVE_LDS];
@@ -419,7 +438,7 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
         wave_zero_bytes(a.dL_dmeans3D + 3 * g0, nrows * 12, lane);
         wave_zero_bytes(a.dL_dscales + 3 * g0, nrows * 12, lane);
         wave_zero_bytes(a.dL_drotations + 4 * g0, nrows * 16, lane);
-        if (a.DIM == 4) wave_zero_bytes(a.dL_dreps + 4 * g0, nrows * 16, lane);
+        if (a.DIM >= 4) wave_zero_bytes(a.dL_dreps + (size_t)a.DIM * g0, nrows * a.DIM * 4, lane);
         wave_zero_bytes(a.dL_dsh_rest + g0 * REST_ROW_F, nrows * REST_ROW_F * 4, lane);
         if (a.row_blocks && lane == 0) a.row_blocks[blk] = 0;
         return;
@@ -430,6 +449,9 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
 
     V3 dmean = v3(0, 0, 0);
     float dop = 0.f, ddc[3] = {0.f, 0.f, 0.f}, drep[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 drepx[WIDE ? 3 : 1];
+#pragma unroll
+    for (int e = 0; e < (WIDE ? 3 : 1); ++e) drepx[e] = make_float4(0, 0, 0, 0);
     float dcov6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     V3 sc = v3(1, 1, 1);
     V4 q = {1, 0, 0, 0};
@@ -513,6 +535,15 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
             drep[1] += g2.w;
             drep[2] += g3.x;
             drep[3] += g3.y;
+            if (WIDE) {
+                const float4* x = bv.accx + 4 * i;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    if (4 * e + 4 >= a.DIM) break;
+                    const float4 xv = x[e];
+                    drepx[e] = make_float4(drepx[e].x + xv.x, drepx[e].y + xv.y, drepx[e].z + xv.z, drepx[e].w + xv.w);
+                }
+            }
         }
     } else if (live) {
 #pragma unroll
@@ -530,7 +561,8 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
             }
         }
         float4* dr = reinterpret_cast<float4*>(a.dL_drotations) + i;
-        float4* dp = reinterpret_cast<float4*>(a.dL_dreps) + i;
+        if (a.DIM >= 4)
+            reps_row_out(a.dL_dreps, i, WIDE ? a.DIM : 4, a.accumulate != 0, make_float4(drep[0], drep[1], drep[2], drep[3]), drepx);
         if (a.accumulate) {
             a.dL_dsh[3 * i] += ddc[0];
             a.dL_dsh[3 * i + 1] += ddc[1];
@@ -544,10 +576,6 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
             a.dL_dscales[3 * i + 2] += ds.z;
             const float4 o = *dr;
             *dr = make_float4(o.x + dq.x, o.y + dq.y, o.z + dq.z, o.w + dq.w);
-            if (a.DIM == 4) {
-                const float4 r = *dp;
-                *dp = make_float4(r.x + drep[0], r.y + drep[1], r.z + drep[2], r.w + drep[3]);
-            }
         } else {
             a.dL_dsh[3 * i] = ddc[0];
             a.dL_dsh[3 * i + 1] = ddc[1];
@@ -560,7 +588,6 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
             a.dL_dscales[3 * i + 1] = ds.y;
             a.dL_dscales[3 * i + 2] = ds.z;
             *dr = make_float4(dq.x, dq.y, dq.z, dq.w);
-            if (a.DIM == 4) *dp = make_float4(drep[0], drep[1], drep[2], drep[3]);
         }
     }
     wave_lds_sync();
@@ -576,17 +603,23 @@ __global__ void __launch_bounds__(256, PRE_BWD_BATCH_WAVES) preprocess_bwd_batch
 // in the forward.  The others are never read (see `rendered` / `seen` above), so a view costs
 // 8 bytes read per Gaussian and 64 written per reached one instead of a 64-byte fill of all.
 // One lane per Gaussian: the hit counts are read coalesced, and only about one record in ten is written.
-__global__ void __launch_bounds__(256) clear_reached_kernel(int P, const GStat* gstat, GradRec* acc) {
+// (accx: the second records of a model with more than four feature channels, or null)
+__global__ void __launch_bounds__(256) clear_reached_kernel(int P, const GStat* gstat, GradRec* acc, float4* accx) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     if (gstat[i].count != 0u) {
         float4* r = reinterpret_cast<float4*>(acc + i);
         r[0] = r[1] = r[2] = r[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (accx) {
+            float4* x = accx + 4 * (size_t)i;
+            x[0] = x[1] = x[2] = x[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
 }
 
-hipError_t launch_clear_reached(int P, const GeomBuf& g, GradRec* acc, hipStream_t st) {
-    hipLaunchKernelGGL(clear_reached_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, g.gstat, acc);
+hipError_t launch_clear_reached(int P, const GeomBuf& g, GradRec* acc, int DIM, hipStream_t st) {
+    hipLaunchKernelGGL(clear_reached_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, g.gstat, acc,
+                       DIM > 4 ? grad_rec_extra(acc, (size_t)P) : (float4*)nullptr);
     return hipGetLastError();
 }
 
@@ -637,6 +670,7 @@ hipError_t launch_preprocess_bwd_batch(const GsrScene& s, int nviews, const GsrB
             bv.clamped = gb.clamped;
             bv.gstat = gb.gstat;
             bv.acc = (const GradRec*)gv.work;
+            bv.accx = grad_rec_extra(gv.work, (size_t)s.P);
             bv.dL_dmeans2D = gv.dL_dmeans2D;
             bv.m2_blocks = gv.dL_dmeans2D ? gv.means2D_blocks : nullptr;
         }
@@ -644,7 +678,8 @@ hipError_t launch_preprocess_bwd_batch(const GsrScene& s, int nviews, const GsrB
             b.v[k] = BatchView();
             b.v[k].gstat = b.v[0].gstat;
         }
-        hipLaunchKernelGGL(preprocess_bwd_batch_kernel, grid, block, 0, st, b);
+        if (s.DIM > 4) hipLaunchKernelGGL(preprocess_bwd_batch_kernel<true>, grid, block, 0, st, b);
+        else hipLaunchKernelGGL(preprocess_bwd_batch_kernel<false>, grid, block, 0, st, b);
     }
     return hipGetLastError();
 }
@@ -660,6 +695,7 @@ hipError_t launch_preprocess_bwd(const GsrScene& s, const int* radii, const Geom
     a.cov3D = s.cov3D_precomp;  // null: recomputed from scales and rotations
     a.cam.view = s.viewmatrix; a.cam.proj = s.projmatrix; a.cam.campos = s.campos;
     a.radii = radii; a.gstat = g.gstat; a.clamped = g.clamped; a.acc = acc;
+    a.accx = grad_rec_extra(acc, (size_t)s.P);
     a.has_invdepth = io.dL_dout_invdepth != nullptr;
     a.dL_dmeans2D = io.dL_dmeans2D; a.dL_dcolors = io.dL_dcolors; a.dL_dopacity = io.dL_dopacity;
     a.dL_dmeans3D = io.dL_dmeans3D; a.dL_dcov3D = io.dL_dcov3D; a.dL_dsh = io.dL_dsh; a.dL_dsh_rest = io.dL_dsh_rest;

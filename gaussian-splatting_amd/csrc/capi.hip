@@ -31,7 +31,7 @@ inline void mark(const GsrScene* s, int slot, hipStream_t st) {
 
 int check_scene(const GsrScene* s) {
     if (!s || s->P < 0 || s->W <= 0 || s->H <= 0) return GSR_ERR_ARG;
-    if (s->DIM != 0 && s->DIM != 4) return GSR_ERR_DIM;
+    if (!reps_dim_supported(s->DIM)) return GSR_ERR_DIM;
     if (s->P == 0) return GSR_OK;
     if (!s->means3D || !s->opacities || !s->viewmatrix || !s->projmatrix || !s->campos || !s->bg) return GSR_ERR_ARG;
     if ((s->shs == nullptr) == (s->colors_precomp == nullptr)) return GSR_ERR_ARG;
@@ -70,7 +70,8 @@ size_t gsr_struct_bytes(int which) {
         default: return 0;
     }
 }
-size_t gsr_backward_work_bytes(int P) { return align_up((size_t)(P > 0 ? P : 1) * sizeof(GradRec), 256); }
+size_t gsr_backward_work_bytes(int P) { return backward_work_bytes((size_t)(P > 0 ? P : 0), 4); }
+size_t gsr_backward_work_bytes_dim(int P, int DIM) { return backward_work_bytes((size_t)(P > 0 ? P : 0), DIM); }
 size_t gsr_sort_temp_error_offset(void) {
     char* const z = (char*)4096;
     return (size_t)((char*)sort_temp_view(z, 1, 0).err - z);
@@ -223,14 +224,14 @@ static int backward_blend(const GsrScene* s, const int* radii, const void* geom_
                           const void* image_buffer, int64_t R, const GsrBackwardIO* io, hipStream_t st) {
     if (!radii || !geom_buffer || !image_buffer || !io->dL_dout_color || !io->work) return GSR_ERR_ARG;
     if (s->DIM > 0 && !io->dL_dout_reps) return GSR_ERR_ARG;
-    if (io->work_bytes < gsr_backward_work_bytes(s->P)) return GSR_ERR_BUFFER;
+    if (io->work_bytes < gsr_backward_work_bytes_dim(s->P, s->DIM)) return GSR_ERR_BUFFER;
     if (R > 0 && !binning_buffer) return GSR_ERR_ARG;
     const bool debug = s->debug != 0;
     const GeomBuf g = geom_buf(geom_buffer, (size_t)s->P);
     const ImageView im = image_view((void*)image_buffer, (size_t)s->W, (size_t)s->H);
     GradRec* acc = (GradRec*)io->work;
     mark(s, GSR_EV_BWD_BEGIN, st);
-    GSR_TRY(launch_clear_reached(s->P, g, acc, st));
+    GSR_TRY(launch_clear_reached(s->P, g, acc, s->DIM, st));
     mark(s, GSR_EV_BWD_CLEAR, st);
     if (R > 0) {
         const BinView b = bin_view((void*)binning_buffer, (size_t)R);
@@ -294,7 +295,7 @@ int gsr_backward_geometry_batch_range(const GsrScene* s, int nviews, const GsrBa
     // the block states (row_blocks, means2D_blocks) are kept per 64 rows: a range ends on a block boundary
     // or at the last Gaussian, so that no call updates the state of a block it handled only part of
     if ((count % 64) != 0 && (int64_t)first + count != s->P) return GSR_ERR_ARG;
-    if (s->DIM != 0 && s->DIM != 4) return GSR_ERR_DIM;
+    if (!reps_dim_supported(s->DIM)) return GSR_ERR_DIM;
     if (s->P == 0 || nviews == 0 || count == 0) return GSR_OK;
     if (!s->means3D || !s->opacities || !s->scales || !s->rotations || !s->shs || !s->shs_rest) return GSR_ERR_ARG;
     if (s->M != 16 || s->D < 0 || s->D > 3 || s->cov3D_precomp || s->colors_precomp) return GSR_ERR_ARG;
@@ -319,7 +320,7 @@ int gsr_backward_geometry_batch_range(const GsrScene* s, int nviews, const GsrBa
 int gsr_preprocess_batch(const GsrScene* s, int nviews, GsrForwardView* views, void* stream) {
     if (!s || nviews < 0 || (nviews > 0 && !views)) return GSR_ERR_ARG;
     if (s->P < 0) return GSR_ERR_ARG;
-    if (s->DIM != 0 && s->DIM != 4) return GSR_ERR_DIM;
+    if (!reps_dim_supported(s->DIM)) return GSR_ERR_DIM;
     if (s->P == 0 || nviews == 0) return GSR_OK;
     if (!s->means3D || !s->opacities || !s->scales || !s->rotations || !s->shs || !s->shs_rest) return GSR_ERR_ARG;
     if (s->M != 16 || s->D < 0 || s->D > 3 || s->cov3D_precomp || s->colors_precomp) return GSR_ERR_ARG;
@@ -630,7 +631,7 @@ const char* gsr_status_string(int status) {
     switch (status) {
         case GSR_OK: return "ok";
         case GSR_ERR_ARG: return "invalid argument";
-        case GSR_ERR_DIM: return "unsupported number of reps channels (supported: 0, 4)";
+        case GSR_ERR_DIM: return "unsupported number of reps channels (supported: 0, 4, 8, 16)";
         case GSR_ERR_OVERFLOW: return "too many Gaussian/tile instances (more than 2^31 - 1)";
         case GSR_ERR_BUFFER: return "caller buffer too small";
         case GSR_ERR_HIP: return "HIP runtime error";

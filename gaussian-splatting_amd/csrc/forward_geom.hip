@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs
                 col = v3(fmax_(col.x, 0.0f), fmax_(col.y, 0.0f), fmax_(col.z, 0.0f));
             }
             float4 rp = make_float4(0, 0, 0, 0);
-            if (a.DIM == 4) rp = reinterpret_cast<const float4*>(a.reps)[idx];
+            if (a.DIM >= 4) rp = *reinterpret_cast<const float4*>(a.reps + (size_t)idx * a.DIM);   // rows of 4, 8 or 16 floats
             float4* r4 = reinterpret_cast<float4*>(a.rec + idx);
             r4[0] = make_float4(sp.xy.x, sp.xy.y, sp.conic_opacity.x, sp.conic_opacity.y);
             r4[1] = make_float4(sp.conic_opacity.z, sp.conic_opacity.w, col.x, col.y);
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_batch_kernel(const P
         }
     }
     float4 rp = make_float4(0, 0, 0, 0);
-    if (b.DIM == 4) rp = reinterpret_cast<const float4*>(b.reps)[i];
+    if (b.DIM >= 4) rp = *reinterpret_cast<const float4*>(b.reps + i * b.DIM);   // rows of 4, 8 or 16 floats
 
 #pragma unroll 1
     for (int v = 0; v < b.nviews; ++v) {

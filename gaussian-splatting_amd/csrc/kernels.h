@@ -68,6 +68,16 @@ struct __attribute__((aligned(16))) GradRec {
 };
 static_assert(sizeof(GradRec) == 64, "GradRec must be 64 bytes");
 
+// Feature ("reps") rows wider than four channels: the gradient sums of channels 4 .. DIM - 1 of every
+// Gaussian live in a second array of 64-byte records behind the GradRecs of the backward work buffer.
+constexpr int REPS_MAX = 16;
+inline bool reps_dim_supported(int DIM) { return DIM == 0 || DIM == 4 || DIM == 8 || DIM == 16; }
+inline size_t grad_rec_bytes(size_t P) { return align_up((P ? P : 1) * sizeof(GradRec), 256); }
+inline float4* grad_rec_extra(const void* work, size_t P) {
+    return work ? reinterpret_cast<float4*>((char*)work + grad_rec_bytes(P)) : nullptr;
+}
+inline size_t backward_work_bytes(size_t P, int DIM) { return grad_rec_bytes(P) * (DIM > 4 ? 2 : 1); }
+
 int sort_passes_for(int begin_bit, int end_bit);
 void render_fwd_set_reach_masks(int mode);   // test hook: 1 / 0 forces the forward blend with / without reach masks, -1 automatic
 void sort_set_force_wide(bool on);   // test hook: 64-bit look-back status words at any size
@@ -152,7 +162,7 @@ hipError_t launch_preprocess_bwd(const GsrScene& s, const int* radii, const Geom
 
 hipError_t launch_means2d_grad(int P, const GeomBuf& g, const GradRec* acc, float* dL_dmeans2D, hipStream_t st);
 // Zeroes the records of the Gaussians that the forward's hit count marks as reached; the rest stay undefined.
-hipError_t launch_clear_reached(int P, const GeomBuf& g, GradRec* acc, hipStream_t st);
+hipError_t launch_clear_reached(int P, const GeomBuf& g, GradRec* acc, int DIM, hipStream_t st);
 // Gaussians [first, first + count) only; first is a multiple of 256.
 hipError_t launch_preprocess_bwd_batch(const GsrScene& s, int nviews, const GsrBackwardView* views,
                                        const GsrBackwardIO& io, int first, int count, hipStream_t st);

@@ -27,6 +27,8 @@ struct RenderBwdArgs {
     const float* dL_dinvdepth;
     const float* dL_dreps;
     float* acc;  // GradRec[P] viewed as floats
+    const float* reps;  // the caller's [P, DIM] tensor: channels 4 .. DIM - 1 come from there (DIM > 4)
+    float* accx;        // [P][16] floats: gradient sums of the feature channels 4 .. DIM - 1 (DIM > 4)
 };
 
 __device__ __forceinline__ int xcd_remap_b(int b, int n) {
@@ -38,10 +40,15 @@ __device__ __forceinline__ int xcd_remap_b(int b, int n) {
 // occupancy is set by the registers (8 waves per SIMD) and not by LDS (4).
 constexpr int BWD_BATCH = 128;
 
+// DIM: feature ("reps") channels, 0, 4, 8 or 16.  The first four are components 10 .. 13 of the GradRec;
+// channels 4 .. DIM - 1 are a second group of up to 12 components with its own staged data, reduction,
+// LDS sums and 64-byte record per Gaussian (accx).
 template <int DIM, bool INVD>
-// 8 waves per SIMD: the register allocator gets 64 VGPRs (it takes 66 when left alone, which costs a wave).
-__global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(8, 8)))
+// 8 waves per SIMD: the register allocator gets 64 VGPRs (it takes 66 when left alone, which costs a wave);
+// the wide-feature instantiations take what they need (4 waves).
+__global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(DIM > 4 ? 4 : 8, DIM > 4 ? 4 : 8)))
 render_bwd_kernel(const RenderBwdArgs a) {
+    constexpr int XQ = DIM > 4 ? (DIM - 4) / 4 : 0;   // extra 16-byte pieces of a feature row
     // same regrouping of the SplatRec as in the forward kernel
     __shared__ float4 s_q[4][BWD_BATCH];
     float4* const s_q0 = s_q[0];  // x, y, -conic.x / 2, -conic.z / 2 (see splat_power_prescaled)
@@ -49,6 +56,8 @@ render_bwd_kernel(const RenderBwdArgs a) {
     float4* const s_q2 = s_q[2];  // r, g, b, 1/depth
     float4* const s_q3 = s_q[3];  // rep0 .. rep3
     __shared__ float s_acc[BWD_BATCH][16];
+    __shared__ float4 s_qx[XQ ? XQ : 1][XQ ? BWD_BATCH : 1];   // rep4 .. rep(DIM - 1)
+    __shared__ float s_accx[XQ ? BWD_BATCH : 1][16];
     __shared__ uint32_t s_max[4];
     // s_reach[q][h]: bit i = entry 64 h + i of the round can give a gradient in quadrant q: one of q's pixels
     // still had it in its list, and its alpha >= 1/255 ellipse reaches the quadrant (quadrant_reach_bits)
@@ -71,16 +80,24 @@ render_bwd_kernel(const RenderBwdArgs a) {
 
     // dL/d(pixel) in the pairing of s_q2 / s_q3: (r, g), (b, 1/depth), reps
     f2 D01 = {0.f, 0.f}, D2i = {0.f, 0.f}, E01 = {0.f, 0.f}, E23 = {0.f, 0.f};
+    f2 EX[XQ ? 2 * XQ : 1];   // dL/d(pixel) of the feature channels 4 .. DIM - 1, in pairs
+#pragma unroll
+    for (int e = 0; e < (XQ ? 2 * XQ : 1); ++e) EX[e] = (f2){0.f, 0.f};
     if (inside) {
         D01.x = a.dL_dpix[pid];
         D01.y = a.dL_dpix[HW + pid];
         D2i.x = a.dL_dpix[2 * HW + pid];
         if (INVD) D2i.y = a.dL_dinvdepth[pid];
-        if (DIM == 4) {
+        if (DIM >= 4) {
             E01.x = a.dL_dreps[pid];
             E01.y = a.dL_dreps[HW + pid];
             E23.x = a.dL_dreps[2 * HW + pid];
             E23.y = a.dL_dreps[3 * HW + pid];
+        }
+#pragma unroll
+        for (int e = 0; e < 2 * XQ; ++e) {
+            EX[e].x = a.dL_dreps[(size_t)(4 + 2 * e) * HW + pid];
+            EX[e].y = a.dL_dreps[(size_t)(5 + 2 * e) * HW + pid];
         }
     }
     float bg_dot_dpixel = 0;
@@ -127,6 +144,11 @@ render_bwd_kernel(const RenderBwdArgs a) {
                 const float4 r3 = r4[3];
                 s_q3[tid] = make_float4(r2.z, r2.w, r3.x, r3.y);
             }
+            if (XQ) {
+                const float4* rx = reinterpret_cast<const float4*>(a.reps + (size_t)id * DIM) + 1;
+#pragma unroll
+                for (int e = 0; e < XQ; ++e) s_qx[e][tid] = rx[e];
+            }
             reach = quadrant_reach_bits(r0.x, r0.y, r0.z, r0.w, r1.x, tau, (float)(tx * TILE_X), (float)(ty * TILE_Y));
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -142,6 +164,10 @@ render_bwd_kernel(const RenderBwdArgs a) {
         {
             float4* z = reinterpret_cast<float4*>(&s_acc[0][0]) + tid;  // 128 x 16 floats = 512 float4
             z[0] = z[TILE_PIX] = make_float4(0, 0, 0, 0);
+            if (XQ) {
+                float4* zx = reinterpret_cast<float4*>(&s_accx[0][0]) + tid;
+                zx[0] = zx[TILE_PIX] = make_float4(0, 0, 0, 0);
+            }
         }
         __syncthreads();
 
@@ -194,7 +220,7 @@ render_bwd_kernel(const RenderBwdArgs a) {
             if (vm == 0) continue;
 
             float4 q2, q3 = make_float4(0, 0, 0, 0);
-            if (DIM == 4)
+            if (DIM >= 4)
                 asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
                              : "=&v"(q2), "=&v"(q3)
                              : "v"(qa), "i"(2 * (int)(BWD_BATCH * sizeof(float4))), "i"(3 * (int)(BWD_BATCH * sizeof(float4)))
@@ -236,11 +262,25 @@ render_bwd_kernel(const RenderBwdArgs a) {
             const f2 g_rg = dc2 * D01;
             const f2 g_bd = dc2 * D2i;
             f2 g_r01 = {0.f, 0.f}, g_r23 = {0.f, 0.f};
-            if (DIM == 4) {
+            if (DIM >= 4) {
                 S2 = __builtin_elementwise_fma((f2){q3.x, q3.y}, E01, S2);
                 S2 = __builtin_elementwise_fma((f2){q3.z, q3.w}, E23, S2);
                 g_r01 = dc2 * E01;
                 g_r23 = dc2 * E23;
+            }
+            float compx[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) compx[e] = 0.f;
+#pragma unroll
+            for (int e = 0; e < XQ; ++e) {
+                const float4 x = s_qx[e][j];
+                S2 = __builtin_elementwise_fma((f2){x.x, x.y}, EX[2 * e], S2);
+                S2 = __builtin_elementwise_fma((f2){x.z, x.w}, EX[2 * e + 1], S2);
+                const f2 ga = dc2 * EX[2 * e], gb = dc2 * EX[2 * e + 1];
+                compx[4 * e] = ga.x;
+                compx[4 * e + 1] = ga.y;
+                compx[4 * e + 2] = gb.x;
+                compx[4 * e + 3] = gb.y;
             }
             const float S = S2.x + S2.y;
             accum_S = fmaf(last_alpha, last_S - accum_S, accum_S);
@@ -271,6 +311,10 @@ render_bwd_kernel(const RenderBwdArgs a) {
                                     g_r01.x, g_r01.y, g_r23.x, g_r23.y, 0.f, 0.f};
             const float tot = wave_transpose_sum16<14>(comp);
             if ((lane & 3) == 0) atomicAdd(&s_acc[j][acc_slot], tot);
+            if (XQ) {
+                const float totx = wave_transpose_sum16<16>(compx);
+                if ((lane & 3) == 0) atomicAdd(&s_accx[j][acc_slot], totx);
+            }
           }
         }
         __syncthreads();
@@ -287,6 +331,10 @@ render_bwd_kernel(const RenderBwdArgs a) {
             }
             v *= scale;
             if (v != 0.0f) atomicAdd(a.acc + (size_t)__float_as_uint(s_q1[j].w) * 16 + (tid & 15), v);
+            if (XQ) {
+                const float vx = s_accx[j][comp_id];
+                if (vx != 0.0f) atomicAdd(a.accx + (size_t)__float_as_uint(s_q1[j].w) * 16 + (tid & 15), vx);
+            }
         }
     }
 }
@@ -308,11 +356,19 @@ hipError_t launch_render_bwd(const GsrScene& s, const GeomBuf& g, const ImageVie
     a.dL_dinvdepth = io.dL_dout_invdepth;
     a.dL_dreps = io.dL_dout_reps;
     a.acc = reinterpret_cast<float*>(acc);
+    a.reps = s.reps;
+    a.accx = reinterpret_cast<float*>(grad_rec_extra(acc, (size_t)s.P));
     const dim3 grid(a.ntiles), block(TILE_PIX);
     const bool invd = io.dL_dout_invdepth != nullptr;
     if (s.DIM == 4) {
         if (invd) hipLaunchKernelGGL((render_bwd_kernel<4, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((render_bwd_kernel<4, false>), grid, block, 0, st, a);
+    } else if (s.DIM == 8) {
+        if (invd) hipLaunchKernelGGL((render_bwd_kernel<8, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((render_bwd_kernel<8, false>), grid, block, 0, st, a);
+    } else if (s.DIM == 16) {
+        if (invd) hipLaunchKernelGGL((render_bwd_kernel<16, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((render_bwd_kernel<16, false>), grid, block, 0, st, a);
     } else {
         if (invd) hipLaunchKernelGGL((render_bwd_kernel<0, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((render_bwd_kernel<0, false>), grid, block, 0, st, a);

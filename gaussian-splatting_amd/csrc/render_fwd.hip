@@ -28,6 +28,7 @@ struct RenderFwdArgs {
     float* accum_alpha;
     int* last_contr;
     float* out_reps;
+    const float* reps;   // the caller's [P, DIM] tensor: channels 4 .. DIM - 1 come from there (DIM > 4)
 };
 
 // Consecutive tile ids land on one XCD (workgroups are dealt round-robin over
@@ -40,8 +41,14 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // REACH: entries whose alpha >= 1/255 ellipse does not reach a wave's quadrant are not tested by that
 // wave (quadrant_reach_bits).  Pays when the splats are small against a tile; costs a scalar test and
 // two scalar copies per visit, which large splats (that reach every quadrant) do not earn back.
+// DIM: feature ("reps") channels, 0, 4, 8 or 16 (the reference fixes them at compile time,
+// cuda_rasterizer/config.h:16).  The first four travel in the SplatRec; wider rows add (DIM - 4) / 4
+// staged 16-byte pieces per entry, fetched from the caller's tensor, and as many accumulators per pixel
+// (those instantiations give up two waves per SIMD for the registers).
 template <int DIM, bool INVD, bool REACH>
-__global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6, 6))) render_fwd_kernel(const RenderFwdArgs a) {
+__global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(DIM > 4 ? 4 : 6, DIM > 4 ? 4 : 6)))
+render_fwd_kernel(const RenderFwdArgs a) {
+    constexpr int XQ = DIM > 4 ? (DIM - 4) / 4 : 0;   // extra 16-byte pieces of a feature row
     // One SplatRec per instance, regrouped: the test of an instance needs the first two
     // quarters only, the other two feed packed (two-float) multiply-adds as they are.
     __shared__ float4 s_q[4][TILE_PIX];
@@ -49,6 +56,7 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
     float4* const s_q1 = s_q[1];  // conic.y, tau, opacity, Gaussian index (bits)
     float4* const s_q2 = s_q[2];  // r, g, b, 1/depth
     float4* const s_q3 = s_q[3];  // rep0 .. rep3
+    __shared__ float4 s_qx[XQ ? XQ : 1][XQ ? TILE_PIX : 1];   // rep4 .. rep(DIM - 1)
     __shared__ float s_gsum[4][TILE_PIX];
     __shared__ uint32_t s_gcnt[4][TILE_PIX];
     __shared__ int s_wdone[4];
@@ -70,6 +78,9 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
     uint64_t live = lanes_where(inside);  // pixels that still accept contributions
     float T = 1.0f;
     f2 Crg = {0.f, 0.f}, Cbd = {0.f, 0.f}, R01 = {0.f, 0.f}, R23 = {0.f, 0.f};  // (r, g), (b, 1/depth), reps
+    f2 RX[XQ ? 2 * XQ : 1];                                                      // reps 4 .. DIM - 1, in pairs
+#pragma unroll
+    for (int e = 0; e < (XQ ? 2 * XQ : 1); ++e) RX[e] = (f2){0.f, 0.f};
     uint32_t last = 0;
     int last_g = -1;
 
@@ -96,6 +107,11 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
             if (DIM > 2) {
                 const float4 r3 = r4[3];
                 s_q3[tid] = make_float4(r2.z, r2.w, r3.x, r3.y);
+            }
+            if (XQ) {
+                const float4* rx = reinterpret_cast<const float4*>(a.reps + (size_t)id * DIM) + 1;
+#pragma unroll
+                for (int e = 0; e < XQ; ++e) s_qx[e][tid] = rx[e];
             }
             if (REACH)
                 reach = quadrant_reach_bits(r0.x, r0.y, r0.z, r0.w, r1.x, tau, (float)(tx * TILE_X), (float)(ty * TILE_Y));
@@ -174,7 +190,7 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
                 const uint64_t bm = am & ~tm;
                 if (bm == 0) continue;
                 float4 q2, q3 = make_float4(0, 0, 0, 0);
-                if (DIM == 4)
+                if (DIM >= 4)
                     asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
                                  : "=&v"(q2), "=&v"(q3)
                                  : "v"(gbase), "i"(2 * (int)(TILE_PIX * sizeof(float4)) + 16 * u),
@@ -194,9 +210,15 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
                     const f2 w2 = {wgt, wgt};
                     Crg = __builtin_elementwise_fma((f2){q2.x, q2.y}, w2, Crg);
                     Cbd = __builtin_elementwise_fma((f2){q2.z, q2.w}, w2, Cbd);
-                    if (DIM == 4) {
+                    if (DIM >= 4) {
                         R01 = __builtin_elementwise_fma((f2){q3.x, q3.y}, w2, R01);
                         R23 = __builtin_elementwise_fma((f2){q3.z, q3.w}, w2, R23);
+                    }
+#pragma unroll
+                    for (int e = 0; e < XQ; ++e) {
+                        const float4 x = s_qx[e][j];
+                        RX[2 * e] = __builtin_elementwise_fma((f2){x.x, x.y}, w2, RX[2 * e]);
+                        RX[2 * e + 1] = __builtin_elementwise_fma((f2){x.z, x.w}, w2, RX[2 * e + 1]);
                     }
                     T = test_T;
                     last = (uint32_t)(base + j + 1);
@@ -236,11 +258,16 @@ __global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(6
         a.out_color[pid] = Crg.x + T * a.bg[0];
         a.out_color[HW + pid] = Crg.y + T * a.bg[1];
         a.out_color[2 * HW + pid] = Cbd.x + T * a.bg[2];
-        if (DIM == 4) {
+        if (DIM >= 4) {
             a.out_reps[pid] = R01.x;
             a.out_reps[HW + pid] = R01.y;
             a.out_reps[2 * HW + pid] = R23.x;
             a.out_reps[3 * HW + pid] = R23.y;
+        }
+#pragma unroll
+        for (int e = 0; e < 2 * XQ; ++e) {
+            a.out_reps[(size_t)(4 + 2 * e) * HW + pid] = RX[e].x;
+            a.out_reps[(size_t)(5 + 2 * e) * HW + pid] = RX[e].y;
         }
         if (INVD) a.out_invdepth[pid] = Cbd.y;
     }
@@ -268,6 +295,7 @@ hipError_t launch_render_fwd(const GsrScene& s, const GsrForwardOut& o, const Ge
     a.accum_alpha = o.accum_alpha;
     a.last_contr = o.last_contr_gauss;
     a.out_reps = o.out_reps;
+    a.reps = s.reps;
     const dim3 grid(a.ntiles), block(TILE_PIX);
     const bool invd = o.out_invdepth != nullptr;
     // small splats (fewer than six tiles per rendered Gaussian on average): the quadrant reach masks pay
@@ -278,6 +306,12 @@ hipError_t launch_render_fwd(const GsrScene& s, const GsrForwardOut& o, const Ge
     if (s.DIM == 4) {
         if (invd) { if (reach) GS_LAUNCH_FWD(4, true, true); else GS_LAUNCH_FWD(4, true, false); }
         else { if (reach) GS_LAUNCH_FWD(4, false, true); else GS_LAUNCH_FWD(4, false, false); }
+    } else if (s.DIM == 8) {
+        if (invd) { if (reach) GS_LAUNCH_FWD(8, true, true); else GS_LAUNCH_FWD(8, true, false); }
+        else { if (reach) GS_LAUNCH_FWD(8, false, true); else GS_LAUNCH_FWD(8, false, false); }
+    } else if (s.DIM == 16) {
+        if (invd) { if (reach) GS_LAUNCH_FWD(16, true, true); else GS_LAUNCH_FWD(16, true, false); }
+        else { if (reach) GS_LAUNCH_FWD(16, false, true); else GS_LAUNCH_FWD(16, false, false); }
     } else {
         if (invd) { if (reach) GS_LAUNCH_FWD(0, true, true); else GS_LAUNCH_FWD(0, true, false); }
         else { if (reach) GS_LAUNCH_FWD(0, false, true); else GS_LAUNCH_FWD(0, false, false); }

@@ -90,8 +90,8 @@ void fill_scene(SceneTensors& t, const torch::Tensor& background, const torch::T
 void check_shapes(const torch::Tensor& means3D, const torch::Tensor& reps) {
     if (means3D.ndimension() != 2 || means3D.size(1) != 3) AT_ERROR("means3D must have dimensions (num_points, 3)");
     if (reps.defined() && reps.numel() != 0) {
-        if (reps.ndimension() != 2 || reps.size(0) != means3D.size(0) || (reps.size(1) != 0 && reps.size(1) != 4))
-            AT_ERROR("reps must have dimensions (num_points, NUM_DIM) with NUM_DIM in (0, 4)");
+        if (reps.ndimension() != 2 || reps.size(0) != means3D.size(0) || (reps.size(1) != 0 && reps.size(1) != 4 && reps.size(1) != 8 && reps.size(1) != 16))
+            AT_ERROR("reps must have dimensions (num_points, NUM_DIM) with NUM_DIM in (0, 4, 8, 16)");
     }
 }
 
@@ -200,7 +200,7 @@ RasterizeGaussiansBackwardHIP(const torch::Tensor& background, const torch::Tens
         torch::Tensor gd = dev_f32(dL_dout_invdepth, dev, "dL_dout_invdepth");
         torch::Tensor gr = DIM ? dev_f32(dL_dout_reps, dev, "dL_dout_reps") : torch::Tensor();
         if (DIM && !gr.defined()) gr = torch::zeros({DIM, H, W}, f32);
-        torch::Tensor work = torch::empty({(int64_t)gsr_backward_work_bytes((int)P)}, means3D.options().dtype(torch::kUInt8));
+        torch::Tensor work = torch::empty({(int64_t)gsr_backward_work_bytes_dim((int)P, DIM)}, means3D.options().dtype(torch::kUInt8));
         GsrBackwardIO io = GsrBackwardIO();
         io.dL_dout_color = fptr(gc);
         io.dL_dout_invdepth = fptr(gd);

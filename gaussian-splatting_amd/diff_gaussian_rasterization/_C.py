@@ -10,7 +10,7 @@ import torch
 from _gsplat_lib import (GsrBackwardIO, GsrBackwardView, GsrForwardOut, GsrForwardView, GsrScene, check, dev_f32, lib,
                          profile_events, ptr, sort_errors, stream_of)
 
-SUPPORTED_DIMS = (0, 4)
+SUPPORTED_DIMS = (0, 4, 8, 16)   # feature channels the blend kernels are instantiated for (the reference: one, at compile time)
 
 # The compiled PyTorch-ROCm host extension (csrc/torch/ext.cpp): the reference's three pybind functions
 # over the C ABI.  The calls below with the reference's own arguments go through it; the ctypes
@@ -223,7 +223,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, opacities, 
             gr = dev_f32(dL_dout_reps, dev, "dL_dout_reps") if DIM else None
             if DIM and gr is None:
                 gr = torch.zeros((DIM, H, W), **f32)
-            work = torch.empty((L.gsr_backward_work_bytes(P),), dtype=torch.uint8, device=dev)
+            work = torch.empty((L.gsr_backward_work_bytes_dim(P, DIM),), dtype=torch.uint8, device=dev)
             io = GsrBackwardIO()
             io.dL_dout_color, io.dL_dout_invdepth, io.dL_dout_reps = ptr(gc), ptr(gd), ptr(gr)
             io.dL_dmeans2D, io.dL_dcolors, io.dL_dopacity = ptr(dL_dmeans2D), ptr(dL_dcolors), ptr(dL_dopacity)
@@ -268,7 +268,7 @@ def rasterize_gaussians_backward_blend(background, means3D, radii, opacities, sc
             dL_dmeans2D = means2D_out
         else:
             dL_dmeans2D = torch.empty((P, 3), **f32)
-        work = torch.empty((L.gsr_backward_work_bytes(P),), dtype=torch.uint8, device=dev)
+        work = torch.empty((L.gsr_backward_work_bytes_dim(P, s.DIM),), dtype=torch.uint8, device=dev)
         if P != 0:
             gc = dev_f32(dL_dout_color, dev, "dL_dout_color")
             gd = dev_f32(dL_dout_invdepth, dev, "dL_dout_invdepth")

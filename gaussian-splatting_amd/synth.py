@@ -93,7 +93,11 @@ def _common_attrs(rng, P, sh_coeffs, dim):
     sh[:, 0, :] = ((rng.random((P, 3)) - 0.5) / SH_C0).astype(np.float32)
     if sh_coeffs > 1:
         sh[:, 1:, :] = (0.05 * rng.standard_normal((P, sh_coeffs - 1, 3))).astype(np.float32)
-    reps = rng.standard_normal((P, dim)).astype(np.float32)
+    # the first four feature channels are the same numbers whatever the width
+    reps = rng.standard_normal((P, 4)).astype(np.float32)
+    if dim != 4:
+        more = np.random.default_rng(977).standard_normal((P, max(dim, 4))).astype(np.float32)
+        reps = np.concatenate([reps, more[:, :dim - 4]], axis=1) if dim > 4 else np.ascontiguousarray(reps[:, :dim])
     return rot, opac, sh, reps
 
 

@@ -41,7 +41,7 @@ extern "C" {
 typedef enum {
     GSR_OK = 0,
     GSR_ERR_ARG = -1,        /* null / inconsistent argument */
-    GSR_ERR_DIM = -2,        /* unsupported number of `reps` channels (supported: 0, 4) */
+    GSR_ERR_DIM = -2,        /* unsupported number of `reps` channels (supported: 0, 4, 8, 16) */
     GSR_ERR_OVERFLOW = -3,   /* more than 2^31 - 1 (Gaussian, tile) instances, the reference's limit (its count is an int) */
     GSR_ERR_BUFFER = -4,     /* a caller buffer is smaller than the matching *_bytes query */
     GSR_ERR_HIP = -5,        /* a HIP runtime call failed */
@@ -56,7 +56,10 @@ typedef struct {
     int P;                 /* number of Gaussians */
     int D;                 /* active SH degree */
     int M;                 /* SH coefficients allocated per Gaussian */
-    int DIM;               /* channels of `reps` (0 or 4) */
+    int DIM;               /* channels of `reps`: 0, 4, 8 or 16.  The reference fixes the number at compile time
+                              (NUM_DIM 4, cuda_rasterizer/config.h:16, which a user edits to match the model's
+                              --dim, arguments/__init__.py:98); here it is a run-time value served by one
+                              instantiation of the blend kernels each */
     int W, H;              /* image size in pixels */
     const float* bg;              /* device [3] */
     const float* means3D;         /* device [P,3] */
@@ -164,7 +167,7 @@ typedef struct {
     float* dL_dscales;       /* device [P,3] or NULL iff scales == NULL */
     float* dL_drotations;    /* device [P,4] or NULL iff rotations == NULL */
     float* dL_dreps;         /* device [P,DIM] or NULL iff DIM == 0 */
-    void* work;              /* device, >= gsr_backward_work_bytes(P) */
+    void* work;              /* device, >= gsr_backward_work_bytes_dim(P, DIM) (= gsr_backward_work_bytes(P) for DIM <= 4) */
     size_t work_bytes;
     float* dL_dsh_rest;      /* device [P,M-1,3] iff scene.shs_rest != NULL (then dL_dsh is [P,1,3]) */
     int accumulate;          /* nonzero: ADD into dL_dmeans3D, dL_dopacity, dL_dsh(+rest), dL_dscales,
@@ -186,6 +189,8 @@ size_t gsr_geom_bytes(int P);
 size_t gsr_image_bytes(int W, int H);
 size_t gsr_binning_bytes(int64_t num_rendered);
 size_t gsr_backward_work_bytes(int P);
+/* The same for a model with DIM feature channels: more than four take a second 64-byte record per Gaussian. */
+size_t gsr_backward_work_bytes_dim(int P, int DIM);
 
 /* Preprocess + prefix sum.  Blocks the host once (as the reference does,
  * rasterizer_impl.cu:338-346) to return the instance count in *num_rendered. */

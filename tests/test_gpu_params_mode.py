@@ -217,12 +217,13 @@ def test_forward_params_matches_reference_formulation(use_sink):
     assert rel_err(m2b.grad.cpu().numpy(), m2a.grad.cpu().numpy()) <= REL_TOL
 
 
-@pytest.mark.parametrize("nviews", [1, 3, 10])
-def test_deferred_batch_backward_matches_per_view_backward(oracle, nviews):
+@pytest.mark.parametrize("nviews,dim", [(1, 4), (3, 4), (10, 4), (3, 8), (10, 16)])
+def test_deferred_batch_backward_matches_per_view_backward(oracle, nviews, dim):
     """ParamGradSink(defer=True): blend backward per view, one per-Gaussian backward for the batch.
-    Compared with the per-view accumulate path and, for the sum, with the CPU checker."""
+    Compared with the per-view accumulate path and, for the sum, with the CPU checker.  dim: feature
+    channels (4 as the reference compiles them, config.h:16; 8 and 16 take the wide instantiations)."""
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, ParamGradSink
-    sc = synth.tiny_scene(P=500, width=96, height=64, seed=23)
+    sc = synth.tiny_scene(P=500, width=96, height=64, seed=23, dim=dim)
     raw = _raw_scene(sc, seed=4)
     t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda:0")
     names = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation", "reps")
@@ -243,7 +244,7 @@ def test_deferred_batch_backward_matches_per_view_backward(oracle, nviews):
             scale_modifier=1.0, viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), sh_degree=3,
             campos=t(cam["campos"]), prefiltered=False, debug=True, antialiasing=True))
     rng = np.random.default_rng(9)
-    ws = [[rng.standard_normal(s).astype(np.float32) for s in ((3, 64, 96), (1, 64, 96), (4, 64, 96))]
+    ws = [[rng.standard_normal(s).astype(np.float32) for s in ((3, 64, 96), (1, 64, 96), (dim, 64, 96))]
           for _ in range(nviews)]
 
     def run(P_, sink, step_scale):

@@ -150,6 +150,43 @@ def test_backward_parity(oracle, name, make, aa, bg, with_depth):
         assert rel_err(got[k], r) <= REL_TOL, (k, rel_err(got[k], r))
 
 
+@pytest.mark.parametrize("dim", [8, 16])
+@pytest.mark.parametrize("name,make,aa,bg", [
+    ("tiny_aa", lambda d: synth.tiny_scene(seed=8, dim=d), True, (1.0, 1.0, 1.0)),
+    ("ragged", lambda d: synth.tiny_scene(P=300, width=75, height=45, seed=9, scale=0.1, dim=d), False, (0.3, 0.6, 0.1)),
+    ("street50k", lambda d: synth.street_scene(50000, 640, 360, seed=3, dim=d), True, (0.1, 0.2, 0.3)),
+    ("deep", lambda d: synth.deep_scene(dim=d), True, (0.0, 0.0, 0.0))], ids=["tiny_aa", "ragged", "street50k", "deep"])
+def test_wide_feature_rows(oracle, dim, name, make, aa, bg):
+    """8 and 16 feature ("reps") channels.  The reference compiles one width in (NUM_DIM, config.h:16; its CLI
+    default --dim is 16, arguments/__init__.py:98); here the width is read off reps.shape[1].  Forward with both
+    blend kernels, backward with and without the inverse-depth gradient, everything against the checker."""
+    from _gsplat_lib import lib
+    sc = make(dim)
+    assert sc["reps"].shape[1] == dim
+    for reach in (0, 1):
+        try:
+            lib().gsr_test_forward_reach_masks(reach)
+            f, out, rs, ten, kw_g = _check_forward(oracle, sc, aa, bg)
+        finally:
+            lib().gsr_test_forward_reach_masks(-1)
+    assert out["out_reps"].shape[0] == dim
+    H, W = rs.image_height, rs.image_width
+    rng = np.random.default_rng(3)
+    gc = rng.standard_normal((3, H, W)).astype(np.float32)
+    gd = rng.standard_normal((1, H, W)).astype(np.float32)
+    gr = rng.standard_normal((dim, H, W)).astype(np.float32)
+    t = lambda a: None if a is None else torch.tensor(a, device="cuda:0")
+    for with_depth in (True, False):
+        ref = f.backward(gc, gd if with_depth else None, gr)
+        got = _grads_gpu(rs, ten, t(gc), t(gd) if with_depth else None, t(gr), kw_g, out)
+        torch.cuda.synchronize()
+        assert got["dL_dreps"].shape == (ten["means3D"].shape[0], dim)
+        for k in got:
+            r = ref[k].reshape(got[k].shape)
+            assert np.isfinite(got[k]).all(), k
+            assert rel_err(got[k], r) <= REL_TOL, (k, rel_err(got[k], r))
+
+
 def test_backward_parity_precomputed(oracle):
     sc = synth.tiny_scene(P=200, width=64, height=48, seed=11)
     f, out, rs, ten, kw_g = _check_forward(oracle, sc, True, (0.2, 0.2, 0.2), precomp=True)
