@@ -95,15 +95,20 @@ int gsr_forward_stage1(const GsrScene* s, GsrForwardOut* o, void* stream, int64_
     const bool debug = s->debug != 0;
     const GeomBuf g = geom_buf(o->geom_buffer, (size_t)s->P);
     mark(s, GSR_EV_STAGE1_BEGIN, st);
+    // prefiltered: the view's flag word (g.total[3]) starts at zero; the preprocess raises it for a culled point
+    const bool check_prefilter = s->prefiltered && !o->preprocessed;
+    if (check_prefilter) GSR_TRY(hipMemsetAsync(g.total + 3, 0, sizeof(uint64_t), st));
     if (!o->preprocessed) GSR_TRY(launch_preprocess_fwd(*s, *o, g, st));
     mark(s, GSR_EV_PREPROCESS, st);
     // gsr_preprocess_batch has run this view's prefix sums already (they are in place: a second scan
     // would scan offsets) and left its three totals in g.total; only the copy is repeated then
     if (!o->preprocessed) GSR_TRY(launch_scan_blocks(g, (s->P + PRE_BLOCK - 1) / PRE_BLOCK, st));
     mark(s, GSR_EV_SCAN, st);
-    uint64_t tot[3] = {0, 0, 0};
-    if (hipMemcpyAsync(tot, g.total, sizeof(tot), hipMemcpyDeviceToHost, st) != hipSuccess) return GSR_ERR_HIP;
+    uint64_t tot[4] = {0, 0, 0, 0};
+    if (hipMemcpyAsync(tot, g.total, (check_prefilter ? 4 : 3) * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess)
+        return GSR_ERR_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return GSR_ERR_HIP;
+    if (check_prefilter && tot[3]) return GSR_ERR_PREFILTER;
     if (tot[1]) return GSR_ERR_OVERFLOW;
     *num_rendered = (int64_t)tot[0];
     o->num_visible = (int64_t)tot[2];
@@ -636,6 +641,7 @@ const char* gsr_status_string(int status) {
         case GSR_ERR_BUFFER: return "caller buffer too small";
         case GSR_ERR_HIP: return "HIP runtime error";
         case GSR_ERR_SORT: return "radix sort look-back did not complete";
+        case GSR_ERR_PREFILTER: return "a point was culled although the caller declared the points prefiltered";
         case GSR_ERR_LIMIT: return "input larger than the fixed scratch of the entry point that does not allocate";
         default: return "unknown status";
     }

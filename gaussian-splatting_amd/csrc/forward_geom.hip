@@ -36,6 +36,7 @@ struct PreArgs {
     uint8_t* clamped;
     uint32_t* block_sums;
     uint32_t* vis_sums;
+    uint32_t* prefilter_flag;   // not null: the caller declared the points prefiltered; set to 1 if one is culled
 };
 
 // MODE: how the SH rows are read (ShMode).  With 16 coefficients a wave first projects its 64 Gaussians,
@@ -62,7 +63,11 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs
     if (live) {
         p = v3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
         float depth;
-        if (!near_cull(p, c.view, &depth)) {
+        const bool culled = near_cull(p, c.view, &depth);
+        // auxiliary.h:181-185: a point culled although the caller said the points were prefiltered.  The
+        // reference prints and traps on the device; here the view's flag is raised and the host call reports it.
+        if (culled && a.prefilter_flag) atomicOr(a.prefilter_flag, 1u);
+        if (!culled) {
             if (a.cov3D_precomp) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) cov6[i] = a.cov3D_precomp[6 * (size_t)idx + i];
@@ -788,6 +793,7 @@ hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, cons
     a.rec = g.rec; a.cov3D = g.cov3D; a.rect = g.rect; a.dt = g.dt; a.gstat = g.gstat; a.clamped = g.clamped;
     a.block_sums = g.block_sums;
     a.vis_sums = g.vis_sums;
+    a.prefilter_flag = s.prefiltered ? reinterpret_cast<uint32_t*>(g.total + 3) : nullptr;   // zeroed by the caller
     const int nb = (s.P + PRE_BLOCK - 1) / PRE_BLOCK;
     const dim3 grid(nb), block(PRE_BLOCK);
     if (!s.shs) hipLaunchKernelGGL(preprocess_fwd_kernel<SH_NONE>, grid, block, 0, st, a);

@@ -22,8 +22,9 @@ struct GeomBuf {
     uint8_t* clamped;     // [P]
     uint32_t* block_sums; // [nblocks+1] tiles per block of 256 Gaussians in index order (gives the total)
     uint32_t* vis_sums;   // [nblocks+1] Gaussians with instances per block, then exclusive offsets
-    uint64_t* total;      // [4] instances, overflow flag, Gaussians with instances; then [3 * SCAN_BATCH_MAX]: the
-                          // same three of every view whose scans ran in one launch with this view as the first
+    uint64_t* total;      // [4] instances, overflow flag, Gaussians with instances, "a point was culled although
+                          // the caller declared them prefiltered"; then [3 * SCAN_BATCH_MAX]: the first
+                          // three of every view whose scans ran in one launch with this view as the first
     uint32_t* dkeys[2];   // [P] depth bits (all ones for Gaussians that are not rendered), ping-pong
     uint32_t* dvals[2];   // [P] Gaussian index, ping-pong; the sorted one is the front-to-back order
     uint4* sbin;          // [P] {x0 | y0<<16, w | h<<16, Gaussian index, tiles} in front-to-back order

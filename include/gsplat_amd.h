@@ -46,7 +46,10 @@ typedef enum {
     GSR_ERR_BUFFER = -4,     /* a caller buffer is smaller than the matching *_bytes query */
     GSR_ERR_HIP = -5,        /* a HIP runtime call failed */
     GSR_ERR_SORT = -6,       /* radix sort look-back did not complete */
-    GSR_ERR_LIMIT = -7       /* input larger than the fixed scratch of gsr_sort_pairs_u64_u32_noalloc */
+    GSR_ERR_LIMIT = -7,      /* input larger than the fixed scratch of gsr_sort_pairs_u64_u32_noalloc */
+    GSR_ERR_PREFILTER = -8   /* scene->prefiltered was set and a point failed the near-plane test: where the reference
+                                prints "Point is filtered although prefiltered is set" and traps on the device
+                                (cuda_rasterizer/auxiliary.h:181-185), gsr_forward_stage1 returns this */
 } GsrStatus;
 
 /* Inputs of one view.  Nullable pointers select the options exactly as the
@@ -75,7 +78,8 @@ typedef struct {
     const float* campos;          /* device [3] */
     float scale_modifier;
     float tanfovx, tanfovy;
-    int prefiltered;
+    int prefiltered;       /* nonzero: the caller asserts that no point is culled; gsr_forward_stage1 checks it
+                              (GSR_ERR_PREFILTER).  gsr_preprocess_batch does not look at it. */
     int antialiasing;
     int debug;             /* nonzero: synchronise and check for errors after every launch */
     void** profile_events; /* NULL, or GSR_NUM_PROFILE_EVENTS hipEvent_t handles that the calls record on

@@ -264,6 +264,38 @@ def test_depth_order_error_of_the_batch_call_reaches_the_views_host_word():
     sort_errors.poll(block=True)
 
 
+def test_prefiltered_violation_is_reported():
+    """`prefiltered=True` promises that no point fails the near-plane test.  Where the reference prints and
+    traps on the device (cuda_rasterizer/auxiliary.h:181-185), the forward call raises; a scene that keeps
+    the promise renders exactly as without the flag.  Both host layers."""
+    import synth
+    from diff_gaussian_rasterization import _C
+    from gpu_util import run_forward_raw, scene_to_torch
+    sc = synth.tiny_scene(P=300, width=64, height=48, seed=3)
+    sc["means3D"][::15, 2] = -10.0                                 # twenty Gaussians behind the camera
+    rs, ten = scene_to_torch(sc, debug=False)
+    ref = run_forward_raw(rs, ten)
+    assert int((ref["radii"] == 0).sum()) > 0
+    pv = np.concatenate([sc["means3D"], np.ones((300, 1), np.float32)], 1) @ sc["camera"]["viewmatrix"]
+    front = pv[:, 2] > 0.2
+    assert 0 < front.sum() < 300
+    ext = _C._hip_ext
+    for layer in ("torch extension", "ctypes"):
+        try:
+            if layer == "ctypes":
+                _C._hip_ext = None
+            assert _C.host_layer() == layer
+            with pytest.raises(RuntimeError, match="prefiltered"):
+                run_forward_raw(rs._replace(prefiltered=True), ten)
+            kept = {k: v[torch.tensor(front, device=v.device)].contiguous() for k, v in ten.items()}
+            a = run_forward_raw(rs._replace(prefiltered=True), kept)
+            b = run_forward_raw(rs, kept)
+            torch.cuda.synchronize()
+            assert a["num_rendered"] == b["num_rendered"] and torch.equal(a["color"], b["color"])
+        finally:
+            _C._hip_ext = ext
+
+
 def test_sort_error_offset_is_inside_the_temp_area():
     from _gsplat_lib import lib
     L = lib()
