@@ -300,6 +300,37 @@ __global__ void __launch_bounds__(256, PRE_BWD_WAVES) preprocess_bwd_kernel(cons
     const bool rendered = live && a.radii[live ? idx : 0] > 0 && a.gstat[live ? idx : 0].count != 0u;
     float* lds = reinterpret_cast<float*>(s_sh + w * WAVE_LDS);
     const uint64_t rows = __ballot(rendered);
+    if (rows == 0) {
+        // No Gaussian of this wave received a gradient (in an occluded scene: nearly every wave).  Each tensor's
+        // block of 64 rows is contiguous: zeroed by whole-wave 16-byte stores in address order, where a lane
+        // storing its own three or six floats makes every store instruction touch 64 lines a fraction full.
+        const size_t g0 = (size_t)wave_g0;
+        wave_zero_bytes(a.dL_dmeans2D + 3 * g0, nrows * 12, lane);
+        if (a.dL_dcolors) wave_zero_bytes(a.dL_dcolors + 3 * g0, nrows * 12, lane);
+        if (a.dL_dcov3D) wave_zero_bytes(a.dL_dcov3D + 6 * g0, nrows * 24, lane);
+        if (a.accumulate) return;  // adding zero: the parameter gradients stay as they are
+        if (MODE == SH_CAT16) {
+            wave_zero_bytes(a.dL_dsh + g0 * SH_ROW_F, nrows * SH_ROW_F * 4, lane);
+        } else if (MODE == SH_SPLIT16) {
+            wave_zero_bytes(a.dL_dsh + 3 * g0, nrows * 12, lane);
+            wave_zero_bytes(a.dL_dsh_rest + g0 * REST_ROW_F, nrows * REST_ROW_F * 4, lane);
+        } else if (MODE == SH_DIRECT) {
+            if (a.shs_rest) {
+                wave_zero_bytes(a.dL_dsh + 3 * g0, nrows * 12, lane);
+                wave_zero_bytes(a.dL_dsh_rest + g0 * (size_t)(a.M - 1) * 3, nrows * (a.M - 1) * 12, lane);
+            } else {
+                wave_zero_bytes(a.dL_dsh + g0 * (size_t)a.M * 3, nrows * a.M * 12, lane);
+            }
+        }
+        wave_zero_bytes(a.dL_dopacity + g0, nrows * 4, lane);
+        wave_zero_bytes(a.dL_dmeans3D + 3 * g0, nrows * 12, lane);
+        if (a.dL_dscales) {
+            wave_zero_bytes(a.dL_dscales + 3 * g0, nrows * 12, lane);
+            wave_zero_bytes(a.dL_drotations + 4 * g0, nrows * 16, lane);
+        }
+        if (a.DIM >= 4) wave_zero_bytes(a.dL_dreps + (size_t)a.DIM * g0, nrows * a.DIM * 4, lane);
+        return;
+    }
     if (MODE == SH_CAT16) {
         if (rows) sh_rows_load(a.shs + (size_t)wave_g0 * SH_ROW_F, reinterpret_cast<float4*>(lds), rows, nrows, lane);
         wave_lds_sync();

@@ -39,6 +39,33 @@ struct PreArgs {
     uint32_t* prefilter_flag;   // not null: the caller declared the points prefiltered; set to 1 if one is culled
 };
 
+// The 64-byte records of a wave's Gaussians (has: this lane has one, q0 .. q3 its four quarters; wave_rec:
+// the record of lane 0).  A lane that stores its own record issues four 16-byte stores 64 bytes apart, so
+// every store instruction of the wave touches 64 line halves a quarter full.  Sixteen records at a time go
+// through LDS instead (sr: 80 float4 of this wave's own, pitch five per record: conflict-free both ways)
+// and leave as ONE store instruction of 64 consecutive 16-byte pieces.
+constexpr int REC_STAGE_F4 = 16 * 5;
+__device__ __forceinline__ void wave_store_records(SplatRec* wave_rec, float4* sr, bool has, float4 q0, float4 q1,
+                                                   float4 q2, float4 q3, int lane) {
+    const uint64_t recs = __ballot(has);
+    float4* const out4 = reinterpret_cast<float4*>(wave_rec);
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+        if (((recs >> (16 * round)) & 0xffffull) == 0) continue;   // wave-uniform
+        if (has && (lane >> 4) == round) {
+            float4* mine = sr + (lane & 15) * 5;
+            mine[0] = q0;
+            mine[1] = q1;
+            mine[2] = q2;
+            mine[3] = q3;
+        }
+        wave_lds_sync();
+        const int r = 16 * round + (lane >> 2);   // the record this lane stores a quarter of
+        if ((recs >> r) & 1ull) out4[4 * r + (lane & 3)] = sr[(lane >> 2) * 5 + (lane & 3)];
+        wave_lds_sync();
+    }
+}
+
 // MODE: how the SH rows are read (ShMode).  With 16 coefficients a wave first projects its 64 Gaussians,
 // then moves the rows of those that are on screen from global memory into LDS as 16-byte chunks in
 // address order (a lane walking its own 192-byte row issues 48 strided dword loads and drags whole
@@ -140,6 +167,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(const PreArgs
             }
             float4 rp = make_float4(0, 0, 0, 0);
             if (a.DIM >= 4) rp = *reinterpret_cast<const float4*>(a.reps + (size_t)idx * a.DIM);   // rows of 4, 8 or 16 floats
+            // (each lane stores its own record here: staging the records through LDS as the batch kernel does
+            // costs this kernel, whose SH rows already take 53 KiB, a workgroup per CU: 0.51 -> 0.63 ms)
             float4* r4 = reinterpret_cast<float4*>(a.rec + idx);
             r4[0] = make_float4(sp.xy.x, sp.xy.y, sp.conic_opacity.x, sp.conic_opacity.y);
             r4[1] = make_float4(sp.conic_opacity.z, sp.conic_opacity.w, col.x, col.y);
@@ -227,6 +256,7 @@ struct PreBatchArgs {
 // projection's registers: 129 VGPRs, 3 waves per SIMD, 1.92 ms instead of 1.53 for 8 views.
 __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_batch_kernel(const PreBatchArgs b) {
     __shared__ float s_col[4][MAX_FWD_BATCH_VIEWS][3][64];
+    __shared__ float4 s_rec[4][REC_STAGE_F4];   // wave_store_records
     __shared__ uint32_t s_tiles[MAX_FWD_BATCH_VIEWS][4];
     __shared__ uint32_t s_vis[MAX_FWD_BATCH_VIEWS][4];
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
@@ -285,6 +315,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_batch_kernel(const P
     for (int v = 0; v < b.nviews; ++v) {
         const FwdBatchView& bv = b.v[v];
         uint32_t tiles = 0;
+        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;   // this lane's record, if it has one
+        bool has_rec = false;
         if (live) {
             const Cam c = load_cam(bv.cam, bv.W, bv.H, bv.tanx, bv.tany, b.mod, b.D, b.M, bv.aa);
             int radius = 0;
@@ -296,11 +328,11 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_batch_kernel(const P
                     V3 col = v3(s_col[w][v][0][lane], s_col[w][v][1][lane], s_col[w][v][2][lane]);
                     bv.clamped[i] = (uint8_t)((col.x < 0 ? 1 : 0) | (col.y < 0 ? 2 : 0) | (col.z < 0 ? 4 : 0));
                     col = v3(fmax_(col.x, 0.0f), fmax_(col.y, 0.0f), fmax_(col.z, 0.0f));
-                    float4* r4 = reinterpret_cast<float4*>(bv.rec + i);
-                    r4[0] = make_float4(sp.xy.x, sp.xy.y, sp.conic_opacity.x, sp.conic_opacity.y);
-                    r4[1] = make_float4(sp.conic_opacity.z, sp.conic_opacity.w, col.x, col.y);
-                    r4[2] = make_float4(col.z, 1 / sp.depth, rp.x, rp.y);
-                    r4[3] = make_float4(rp.z, rp.w, sp.depth, 0.0f);
+                    q0 = make_float4(sp.xy.x, sp.xy.y, sp.conic_opacity.x, sp.conic_opacity.y);
+                    q1 = make_float4(sp.conic_opacity.z, sp.conic_opacity.w, col.x, col.y);
+                    q2 = make_float4(col.z, 1 / sp.depth, rp.x, rp.y);
+                    q3 = make_float4(rp.z, rp.w, sp.depth, 0.0f);
+                    has_rec = true;
                     bv.out_depths[i] = sp.depth;
                     radius = sp.radius;
                     tiles = sp.tiles;
@@ -315,6 +347,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_batch_kernel(const P
             bv.dt[i] = make_uint2(bin.z, bin.w);
             bv.gstat[i] = GStat{0.0f, 0u};
         }
+        wave_store_records(bv.rec + ((size_t)blockIdx.x * PRE_BLOCK + w * 64), s_rec[w], has_rec, q0, q1, q2, q3, lane);
         const uint32_t ws = wave_sum_u32(tiles);
         const uint32_t wv = (uint32_t)__popcll(__ballot(tiles > 0));
         if (lane == 0) {
