@@ -721,10 +721,61 @@ def main():
             with torch.no_grad():
                 render_reference_api(params, rs0)
 
+        def reference_breakdown(n=10):
+            """Where an iteration through the unchanged reference signature spends its time, from events
+            on the stream: the model's activations and torch.cat (scene/gaussian_model.py:470-502), the
+            rasterizer forward (the extension call: allocations, kernels and the one host block), the loss as
+            train.py:222-251 composes it, its backward, and the backward through the rasterizer, split into
+            the library's own kernels (its profile events) and what autograd does around them (activation
+            backward, the split of the concatenated SH gradient, accumulation into .grad)."""
+            from diff_gaussian_rasterization import GaussianRasterizer
+            tm = KernelTimer(1)
+            acc = {}
+            for i in range(n + 1):
+                for p in leaves:
+                    p.grad = None
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+                tm.arm(0)
+                e[0].record()
+                means2D = torch.zeros_like(params["xyz"], requires_grad=True)
+                shs = torch.cat((params["features_dc"], params["features_rest"]), dim=1)
+                op, sc_, rot = (torch.sigmoid(params["opacity"]), torch.exp(params["scaling"]),
+                                torch.nn.functional.normalize(params["rotation"]))
+                e[1].record()
+                o = GaussianRasterizer(rs0)(means3D=params["xyz"], means2D=means2D, opacities=op, shs=shs, scales=sc_,
+                                            rotations=rot, reps=params["reps"])
+                e[2].record()
+                loss = train_loss(o, gt0)
+                e[3].record()
+                g_img, g_rep = torch.autograd.grad(loss, [o[0], o[5]])
+                e[4].record()
+                torch.autograd.backward([o[0], o[5]], [g_img, g_rep])
+                e[5].record()
+                torch.cuda.synchronize()
+                tm.arm(None)
+                if i == 0:
+                    continue
+                ev = tm.events[0]
+                cur = {"activations_and_cat": e[0].elapsed_time(e[1]), "rasterizer_forward": e[1].elapsed_time(e[2]),
+                       "loss_forward": e[2].elapsed_time(e[3]), "loss_backward": e[3].elapsed_time(e[4]),
+                       "backward_through_rasterizer": e[4].elapsed_time(e[5]),
+                       "rasterizer_forward_kernels": ev[0].elapsed_time(ev[2]) + ev[3].elapsed_time(ev[9]),
+                       "rasterizer_backward_kernels": ev[10].elapsed_time(ev[13])}
+                for k, v in cur.items():
+                    acc[k] = acc.get(k, 0.0) + v / n
+            acc["autograd_around_the_rasterizer_backward"] = (acc["backward_through_rasterizer"] -
+                                                              acc["rasterizer_backward_kernels"])
+            acc["iteration"] = sum(acc[k] for k in ("activations_and_cat", "rasterizer_forward", "loss_forward",
+                                                    "loss_backward", "backward_through_rasterizer"))
+            acc["library_kernels_share"] = (acc["rasterizer_forward_kernels"] + acc["rasterizer_backward_kernels"]) / \
+                acc["iteration"]
+            return {k: round(v, 4) for k, v in acc.items()}
+
         if use_params:
             extras["single_view_it_s"] = timed(it_params, 20)
         saved = [p.grad for p in leaves]
         extras["reference_api_it_s"] = timed(it_reference, 20)
+        extras["reference_api_breakdown_ms"] = reference_breakdown()
         for p, g in zip(leaves, saved):
             p.grad = g
         extras["render_fps"] = timed(fps_params, 20)

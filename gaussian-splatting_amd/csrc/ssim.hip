@@ -23,60 +23,120 @@ __device__ __forceinline__ float ssim_ld(const float* img, int y, int x, int H, 
     return (x >= 0 && x < W && y >= 0 && y < H) ? img[(size_t)y * W + x] : 0.0f;
 }
 
+// The halo loads of a workgroup, all in flight at once: each thread fetches its SS_LD elements of the
+// 42 x 42 halo (element tid + 256 k) with unconditional loads from clamped coordinates and zeroes what lies
+// outside the image afterwards (zero padding, ssim.cu:36-42).  Written as a loop over conditional loads, the
+// compiler waits for every round's loads before it issues the next: seven memory round trips in a row per
+// workgroup, which is what these kernels spent most of their time on.
+constexpr int SS_LD = (SS_H * SS_H + 255) / 256;
+template <int N>
+__device__ __forceinline__ void ssim_halo_load(const float* const (&img)[N], int y0, int x0, int H, int W, int tid,
+                                               float (&v)[N][SS_LD]) {
+#pragma unroll
+    for (int k = 0; k < SS_LD; ++k) {
+        const int i = min(tid + 256 * k, SS_H * SS_H - 1);
+        const int ly = i / SS_H, lx = i - ly * SS_H;
+        const int y = y0 + ly - 5, x = x0 + lx - 5;
+        const size_t at = (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
+#pragma unroll
+        for (int c = 0; c < N; ++c) v[c][k] = img[c][at];
+    }
+#pragma unroll
+    for (int k = 0; k < SS_LD; ++k) {
+        const int i = min(tid + 256 * k, SS_H * SS_H - 1);
+        const int ly = i / SS_H, lx = i - ly * SS_H;
+        const int y = y0 + ly - 5, x = x0 + lx - 5;
+        const bool in = x >= 0 && x < W && y >= 0 && y < H;
+#pragma unroll
+        for (int c = 0; c < N; ++c) v[c][k] = in ? v[c][k] : 0.0f;
+    }
+}
+
 // LOSS: the training loss of train.py:222-230 around the map.  img1 is the unclamped render: it is
 // clamped to [0, 1] on the way into LDS (gaussian_renderer/__init__.py:179); no map is stored, instead
 // the workgroup's sums of |img1 - img2| and of the map go to partial[2 * workgroup] (+1), in a fixed
 // order, for the finishing kernel.
 __device__ __forceinline__ float clamp01(float x) { return fmin_(fmax_(x, 0.0f), 1.0f); }
 
+// Horizontal pass: one work item = SS_HG neighbouring outputs of one halo row from a sliding window of
+// SS_HG + 10 inputs; 42 rows x 4 items = 168 items, one round of the 256 threads.  The results wait in
+// registers across a barrier and then go to LDS OVER the halo they were computed from: the filtered rows
+// and the halo are never live together, so the workgroup needs 26.9 KB instead of 41.3 (forward) and five
+// or six workgroups fit a CU instead of three.
+constexpr int SS_HG = 8;
+constexpr int SS_HITEMS = SS_H * (SS_T / SS_HG);
+static_assert(SS_HITEMS <= 256, "the horizontal pass is one round of the workgroup");
+
 template <bool LOSS>
 __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, float C1, float C2, const float* __restrict__ img1,
                                                        const float* __restrict__ img2, float* __restrict__ ssim_map,
                                                        float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
                                                        float* __restrict__ dm_dsigma12, float* __restrict__ partial) {
-    __shared__ float s_a[SS_H][SS_H + 1];
-    __shared__ float s_b[SS_H][SS_H + 1];
-    __shared__ __align__(16) float s_x[5][SS_H][SS_T];  // mu1, E[x^2], mu2, E[y^2], E[xy] after the horizontal pass
+    constexpr int HALO_F = 2 * SS_H * (SS_H + 1), ROWS_F = 5 * SS_H * SS_T;
+    __shared__ __align__(16) float s_mem[HALO_F > ROWS_F ? HALO_F : ROWS_F];
+    float (*s_a)[SS_H + 1] = reinterpret_cast<float (*)[SS_H + 1]>(s_mem);
+    float (*s_b)[SS_H + 1] = reinterpret_cast<float (*)[SS_H + 1]>(s_mem + SS_H * (SS_H + 1));
+    // mu1, E[x^2], mu2, E[y^2], E[xy] after the horizontal pass (same memory as the halo)
+    float (*s_x)[SS_H][SS_T] = reinterpret_cast<float (*)[SS_H][SS_T]>(s_mem);
     const size_t plane = (size_t)blockIdx.z * H * W;
     const float* a = img1 + plane;
     const float* b = img2 + plane;
     const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < SS_H * SS_H; i += 256) {
-        const int ly = i / SS_H, lx = i - ly * SS_H;
-        const float va = ssim_ld(a, y0 + ly - 5, x0 + lx - 5, H, W);
-        s_a[ly][lx] = LOSS ? clamp01(va) : va;
-        s_b[ly][lx] = ssim_ld(b, y0 + ly - 5, x0 + lx - 5, H, W);
+    float sum_l1 = 0.f, sum_m = 0.f;
+    {
+        const float* const src[2] = {a, b};
+        float v[2][SS_LD];
+        ssim_halo_load<2>(src, y0, x0, H, W, tid, v);
+#pragma unroll
+        for (int k = 0; k < SS_LD; ++k) {
+            const int i = tid + 256 * k;
+            if (i < SS_H * SS_H) {
+                const int ly = i / SS_H, lx = i - ly * SS_H;
+                const float pa = LOSS ? clamp01(v[0][k]) : v[0][k];
+                s_a[ly][lx] = pa;
+                s_b[ly][lx] = v[1][k];
+                // the L1 part of the loss, over the pixels of the tile proper that lie inside the image
+                if (LOSS && ly >= 5 && ly < 5 + SS_T && lx >= 5 && lx < 5 + SS_T && y0 + ly - 5 < H && x0 + lx - 5 < W)
+                    sum_l1 += fabsf(pa - v[1][k]);
+            }
+        }
     }
     __syncthreads();
-    for (int i = tid; i < SS_H * (SS_T / 4); i += 256) {
-        const int ly = i / (SS_T / 4), lx = (i - ly * (SS_T / 4)) * 4;
-        float v[5][4];
+    float hv[5][SS_HG];
+    const int hy = tid / (SS_T / SS_HG), hx = (tid - hy * (SS_T / SS_HG)) * SS_HG;
+    if (tid < SS_HITEMS) {
 #pragma unroll
         for (int c = 0; c < 5; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[c][r] = 0.f;
+            for (int r = 0; r < SS_HG; ++r) hv[c][r] = 0.f;
 #pragma unroll
-        for (int j = 0; j < GS_SSIM_TAPS + 3; ++j) {
-            const float pa = s_a[ly][lx + j], pb = s_b[ly][lx + j];
+        for (int j = 0; j < GS_SSIM_TAPS + SS_HG - 1; ++j) {
+            const float pa = s_a[hy][hx + j], pb = s_b[hy][hx + j];
             const float aa = pa * pa, bb = pb * pb, ab = pa * pb;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = j - r;  // output lx + r sees this input as its tap k
+            for (int r = 0; r < SS_HG; ++r) {
+                const int k = j - r;  // output hx + r sees this input as its tap k
                 if (k >= 0 && k < GS_SSIM_TAPS) {
                     const float g = ssim_tap(k);
-                    v[0][r] = fmaf(g, pa, v[0][r]);
-                    v[1][r] = fmaf(g, aa, v[1][r]);
-                    v[2][r] = fmaf(g, pb, v[2][r]);
-                    v[3][r] = fmaf(g, bb, v[3][r]);
-                    v[4][r] = fmaf(g, ab, v[4][r]);
+                    hv[0][r] = fmaf(g, pa, hv[0][r]);
+                    hv[1][r] = fmaf(g, aa, hv[1][r]);
+                    hv[2][r] = fmaf(g, pb, hv[2][r]);
+                    hv[3][r] = fmaf(g, bb, hv[3][r]);
+                    hv[4][r] = fmaf(g, ab, hv[4][r]);
                 }
             }
         }
+    }
+    __syncthreads();   // every read of the halo is done: its memory takes the filtered rows
+    if (tid < SS_HITEMS) {
 #pragma unroll
         for (int c = 0; c < 5; ++c)
-            *reinterpret_cast<float4*>(&s_x[c][ly][lx]) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+#pragma unroll
+            for (int q = 0; q < SS_HG / 4; ++q)
+                *reinterpret_cast<float4*>(&s_x[c][hy][hx + 4 * q]) =
+                    make_float4(hv[c][4 * q], hv[c][4 * q + 1], hv[c][4 * q + 2], hv[c][4 * q + 3]);
     }
     __syncthreads();
     const int lx = tid & 31, ly0 = (tid >> 5) * 4;
@@ -100,19 +160,14 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, float C1, f
             }
         }
     }
-    float sum_l1 = 0.f, sum_m = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int px = x0 + lx, py = y0 + ly0 + r;
         if (px < W && py < H) {
             const SsimOut o = ssim_point(v[0][r], v[1][r], v[2][r], v[3][r], v[4][r], C1, C2);
             const size_t gi = plane + (size_t)py * W + px;
-            if (LOSS) {
-                sum_m += o.m;
-                sum_l1 += fabsf(s_a[ly0 + r + 5][lx + 5] - s_b[ly0 + r + 5][lx + 5]);
-            } else {
-                ssim_map[gi] = o.m;
-            }
+            if (LOSS) sum_m += o.m;
+            else ssim_map[gi] = o.m;
             if (dm_dmu1) {
                 dm_dmu1[gi] = o.dm_dmu1;
                 dm_dsigma1_sq[gi] = o.dm_dsigma1_sq;
@@ -176,45 +231,65 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, const float
                                                        const float* __restrict__ dm_dsigma1_sq,
                                                        const float* __restrict__ dm_dsigma12, float lambda,
                                                        float inv_count) {
-    __shared__ float s_p[3][SS_H][SS_H + 1];  // dL * (dm_dmu1, dm_dsigma1_sq, dm_dsigma12)
-    __shared__ __align__(16) float s_x[3][SS_H][SS_T];
+    constexpr int HALO_F = 3 * SS_H * (SS_H + 1), ROWS_F = 3 * SS_H * SS_T;
+    __shared__ __align__(16) float s_mem[HALO_F > ROWS_F ? HALO_F : ROWS_F];
+    // dL * (dm_dmu1, dm_dsigma1_sq, dm_dsigma12), and over it, later, the rows after the horizontal pass
+    float (*s_p)[SS_H][SS_H + 1] = reinterpret_cast<float (*)[SS_H][SS_H + 1]>(s_mem);
+    float (*s_x)[SS_H][SS_T] = reinterpret_cast<float (*)[SS_H][SS_T]>(s_mem);
     const size_t plane = (size_t)blockIdx.z * H * W;
     const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
     const int tid = threadIdx.x;
-    for (int i = tid; i < SS_H * SS_H; i += 256) {
-        const int ly = i / SS_H, lx = i - ly * SS_H;
-        const int y = y0 + ly - 5, x = x0 + lx - 5;
-        const float dl = LOSS ? (-lambda * inv_count) * dL_dmap[0] : ssim_ld(dL_dmap + plane, y, x, H, W);
-        s_p[0][ly][lx] = ssim_ld(dm_dmu1 + plane, y, x, H, W) * dl;
-        s_p[1][ly][lx] = ssim_ld(dm_dsigma1_sq + plane, y, x, H, W) * dl;
-        s_p[2][ly][lx] = ssim_ld(dm_dsigma12 + plane, y, x, H, W) * dl;
+    {
+        // LOSS: dL/dmap is one number; the fourth array then is a stand-in that is loaded and not used
+        const float* const src[4] = {dm_dmu1 + plane, dm_dsigma1_sq + plane, dm_dsigma12 + plane,
+                                     LOSS ? dm_dmu1 + plane : dL_dmap + plane};
+        float v[4][SS_LD];
+        ssim_halo_load<4>(src, y0, x0, H, W, tid, v);
+        const float dl_all = LOSS ? (-lambda * inv_count) * dL_dmap[0] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < SS_LD; ++k) {
+            const int i = tid + 256 * k;
+            if (i < SS_H * SS_H) {
+                const int ly = i / SS_H, lx = i - ly * SS_H;
+                const float dl = LOSS ? dl_all : v[3][k];
+                s_p[0][ly][lx] = v[0][k] * dl;
+                s_p[1][ly][lx] = v[1][k] * dl;
+                s_p[2][ly][lx] = v[2][k] * dl;
+            }
+        }
     }
     __syncthreads();
-    for (int i = tid; i < SS_H * (SS_T / 4); i += 256) {
-        const int ly = i / (SS_T / 4), lx = (i - ly * (SS_T / 4)) * 4;
-        float v[3][4];
+    float hv[3][SS_HG];
+    const int hy = tid / (SS_T / SS_HG), hx = (tid - hy * (SS_T / SS_HG)) * SS_HG;
+    if (tid < SS_HITEMS) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[c][r] = 0.f;
+            for (int r = 0; r < SS_HG; ++r) hv[c][r] = 0.f;
 #pragma unroll
-        for (int j = 0; j < GS_SSIM_TAPS + 3; ++j) {
+        for (int j = 0; j < GS_SSIM_TAPS + SS_HG - 1; ++j) {
             float in[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) in[c] = s_p[c][ly][lx + j];
+            for (int c = 0; c < 3; ++c) in[c] = s_p[c][hy][hx + j];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < SS_HG; ++r) {
                 const int k = j - r;
                 if (k >= 0 && k < GS_SSIM_TAPS) {
                     const float g = ssim_tap(k);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) v[c][r] = fmaf(g, in[c], v[c][r]);
+                    for (int c = 0; c < 3; ++c) hv[c][r] = fmaf(g, in[c], hv[c][r]);
                 }
             }
         }
+    }
+    __syncthreads();   // every read of the halo is done: its memory takes the filtered rows
+    if (tid < SS_HITEMS) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            *reinterpret_cast<float4*>(&s_x[c][ly][lx]) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+#pragma unroll
+            for (int q = 0; q < SS_HG / 4; ++q)
+                *reinterpret_cast<float4*>(&s_x[c][hy][hx + 4 * q]) =
+                    make_float4(hv[c][4 * q], hv[c][4 * q + 1], hv[c][4 * q + 2], hv[c][4 * q + 3]);
     }
     __syncthreads();
     const int lx = tid & 31, ly0 = (tid >> 5) * 4;
