@@ -1,4 +1,5 @@
-"""Times fused_ssim.l1_ssim_loss forward + backward on one 3 x H x W image (HIP events, mean of 200 runs).
+"""Times fused_ssim.l1_ssim_loss on one 3 x H x W image plus l1_loss on a 4 x H x W feature image, forward +
+backward (HIP events, mean of 200 runs).
 usage: time_loss.py [W H]"""
 import os
 import sys
@@ -13,11 +14,13 @@ W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 108
 g = torch.Generator(device="cuda").manual_seed(0)
 img = torch.rand((3, H, W), device="cuda", generator=g).requires_grad_(True)
 gt = torch.rand((3, H, W), device="cuda", generator=g)
+rep = (10 * torch.rand((4, H, W), device="cuda", generator=g)).requires_grad_(True)
 
 
 def once():
     img.grad = None
-    fused_ssim.l1_ssim_loss(img, gt).backward()
+    rep.grad = None
+    (fused_ssim.l1_ssim_loss(img, gt) + 0.01 * fused_ssim.l1_loss(rep, 10.0)).backward()
 
 
 for _ in range(20):
@@ -29,4 +32,4 @@ for _ in range(200):
     once()
 e1.record()
 torch.cuda.synchronize()
-print("l1_ssim_loss fwd+bwd %dx%d: %.4f ms" % (W, H, e0.elapsed_time(e1) / 200))
+print("l1_ssim_loss + l1_loss fwd+bwd %dx%d: %.4f ms" % (W, H, e0.elapsed_time(e1) / 200))
