@@ -901,16 +901,17 @@ def main():
         achieved = ab / (kernels[dom] * 1e-3) / 1e9
         # Vector-instruction issue: wave64 instructions a launch executes (SQ_INSTS_VALU of the committed PMC passes
         # of this command) over the live duration, against 1024 SIMDs x 0.5 instructions per clock (a wave64
-        # instruction issues over 2 cycles on a 32-lane SIMD) at the clock the counters show.
+        # instruction issues over 2 cycles on a 32-lane SIMD) at the nominal 2.4 GHz.  (The clock the counter
+        # passes ran at is reported beside it; it belongs to the box of that collection, not to this run, so it
+        # does not enter the peak: a slower box there must not flatter the fraction here.)
         valu = {} if pmc_stale else load_pmc_valu(P, W, H, args.scene)
         for k, ent in per_kernel.items():
             if k in valu:
                 v = valu[k]
-                clk = min(v.get("clock_GHz") or 2.4, 2.4)   # short kernels: the busy counter runs past the kernel
-                peak = 1024 * 0.5 * clk      # G wave-instructions / s
+                peak = 1024 * 0.5 * 2.4      # G wave-instructions / s
                 rate = v["valu_insts"] / (ent["ms"] * 1e-3) / 1e9
                 ent["valu"] = {"wave_insts_per_launch": v["valu_insts"], "achieved_Ginst_s": rate, "peak_Ginst_s": peak,
-                               "frac": rate / peak,
+                               "frac": rate / peak, "clock_GHz_of_the_pmc_passes": v.get("clock_GHz"),
                                # how full the vector pipes were: the cycles vector instructions kept their SIMD
                                # (SQ_ACTIVE_INST_VALU, units of 4 cycles) over 1024 SIMDs x the launch's cycles
                                "simd_busy_frac": (v["valu_active_simd_cycles"] / (1024.0 * v["launch_cycles"])
