@@ -91,6 +91,8 @@ def lib():
     L.gsr_test_forward_reach_masks.argtypes = [C.c_int]
     L.gsr_test_packed_instances.restype = None
     L.gsr_test_packed_instances.argtypes = [C.c_int]
+    L.gsr_test_wide_depth_keys.restype = None
+    L.gsr_test_wide_depth_keys.argtypes = [C.c_int]
     L.gsr_test_inject_sort_error.restype = None
     L.gsr_test_inject_sort_error.argtypes = [C.c_int]
     L.gsr_sort_noalloc_error.restype = C.c_int
@@ -177,7 +179,7 @@ def lib():
 
 EXPORTED = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_backward_work_bytes", "gsr_backward_work_bytes_dim",
             "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_backward_blend",
-            "gsr_backward_geometry_batch", "gsr_backward_geometry_batch_range", "gsr_preprocess_batch", "gsr_mark_visible", "gsr_sort_temp_bytes", "gsr_sort_temp_error_offset", "gsr_test_inject_sort_error", "gsr_test_force_wide_sort_status", "gsr_test_forward_reach_masks", "gsr_test_packed_instances",
+            "gsr_backward_geometry_batch", "gsr_backward_geometry_batch_range", "gsr_preprocess_batch", "gsr_mark_visible", "gsr_sort_temp_bytes", "gsr_sort_temp_error_offset", "gsr_test_inject_sort_error", "gsr_test_force_wide_sort_status", "gsr_test_forward_reach_masks", "gsr_test_packed_instances", "gsr_test_wide_depth_keys",
             "gsr_sort_pairs_u64_u32", "gsr_sort_noalloc_max_pairs", "gsr_sort_pairs_u64_u32_noalloc", "gsr_sort_noalloc_error", "gsr_layout", "gsr_sorted_keys_u64", "gsk_dist2_temp_bytes", "gsk_dist2", "gss_ssim_forward",
             "gss_ssim_backward", "gss_loss_partial_floats", "gss_l1_ssim_loss_forward", "gss_l1_ssim_loss_backward",
             "gss_l1_partial_floats", "gss_l1_loss_forward", "gss_l1_loss_backward",

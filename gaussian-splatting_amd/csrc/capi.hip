@@ -12,6 +12,10 @@ namespace {
 
 thread_local int t_inject_sort_error = 0;  // test hook only (gsr_test_inject_sort_error): 1 instance sort, 2 depth sort
 thread_local int t_packed_sort = 1;        // test hook only (gsr_test_packed_instances)
+#ifndef GS_WIDE_DEPTH_KEYS
+#define GS_WIDE_DEPTH_KEYS 0   // (1: builds a library for A/B timing that always orders by all 32 depth bits)
+#endif
+thread_local int t_wide_depth_keys = GS_WIDE_DEPTH_KEYS;    // test hook only (gsr_test_wide_depth_keys)
 
 inline int hip_status(hipError_t e) { return e == hipSuccess ? GSR_OK : GSR_ERR_HIP; }
 
@@ -80,6 +84,7 @@ void gsr_test_force_wide_sort_status(int on) { sort_set_force_wide(on != 0); }
 void gsr_test_forward_reach_masks(int mode) { render_fwd_set_reach_masks(mode); }
 void gsr_test_inject_sort_error(int which) { t_inject_sort_error = which == 2 ? 2 : (which ? 1 : 0); }
 void gsr_test_packed_instances(int on) { t_packed_sort = on ? 1 : 0; }
+void gsr_test_wide_depth_keys(int on) { t_wide_depth_keys = on ? 1 : 0; }
 size_t gsr_sort_temp_bytes(int64_t n) { return sort_temp_view(nullptr, (size_t)(n > 0 ? n : 1), SORT_MAX_PASSES).bytes; }
 
 int gsr_forward_stage1(const GsrScene* s, GsrForwardOut* o, void* stream, int64_t* num_rendered) {
@@ -342,15 +347,21 @@ int gsr_preprocess_batch(const GsrScene* s, int nviews, GsrForwardView* views, v
     hipStream_t st = (hipStream_t)stream;
     const bool debug = s->debug != 0;
     mark(s, GSR_EV_FWD_BATCH_BEGIN, st);
-    GSR_TRY(launch_preprocess_fwd_batch(*s, nviews, views, st));
+    // one word for the whole call, in the first view's buffer: "some depth reaches DEPTH_KEY_FAR"
+    uint64_t* const far_flag = geom_buf(views[0].geom_buffer, (size_t)s->P).total + 4 + 3 * SCAN_BATCH_MAX;
+    GSR_TRY(hipMemsetAsync(far_flag, 0, sizeof(uint64_t), st));
+    GSR_TRY(launch_preprocess_fwd_batch(*s, nviews, views, reinterpret_cast<uint32_t*>(far_flag), st));
     mark(s, GSR_EV_FWD_BATCH, st);
     // prefix sums of every view, then all the totals with one host block
     // (the scans of up to 16 views in one launch, their totals collected for one copy)
     constexpr int CHUNK = SCAN_BATCH_MAX;
+    uint64_t far = 1;
     for (int v0 = 0; v0 < nviews; v0 += CHUNK) {
         const int n = nviews - v0 < CHUNK ? nviews - v0 : CHUNK;
         uint64_t tot[CHUNK][3];
         GeomBuf gb[CHUNK];
+        if (v0 == 0 && hipMemcpyAsync(&far, far_flag, sizeof(far), hipMemcpyDeviceToHost, st) != hipSuccess)
+            return GSR_ERR_HIP;   // (completes with the wait for the first chunk's totals)
         for (int k = 0; k < n; ++k) gb[k] = geom_buf(views[v0 + k].geom_buffer, (size_t)s->P);
         uint64_t* all = nullptr;
         GSR_TRY(launch_scan_blocks_batch(n, gb, (s->P + PRE_BLOCK - 1) / PRE_BLOCK, st, &all));
@@ -379,8 +390,9 @@ int gsr_preprocess_batch(const GsrScene* s, int nviews, GsrForwardView* views, v
             which[m++] = v0;
         }
         if (m == 0) continue;
-        GSR_TRY(launch_depth_order_batch(m, gb, s->P, nvis, st));
-        for (int k = 0; k < m; ++k) views[which[k]].depth_ordered = 1;
+        const bool narrow = far == 0 && !t_wide_depth_keys;
+        GSR_TRY(launch_depth_order_batch(m, gb, s->P, nvis, narrow, st));
+        for (int k = 0; k < m; ++k) views[which[k]].depth_ordered = narrow ? 2 : 1;
     }
     mark(s, GSR_EV_FWD_BATCH_SORT, st);
 #endif

@@ -246,6 +246,7 @@ struct PreBatchArgs {
     const float* rotations;
     const float* reps;
     int nviews;
+    uint32_t* far_flag;   // set when a depth in front of a near plane reaches DEPTH_KEY_FAR
     FwdBatchView v[MAX_FWD_BATCH_VIEWS];
 };
 
@@ -310,6 +311,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_batch_kernel(const P
     }
     float4 rp = make_float4(0, 0, 0, 0);
     if (b.DIM >= 4) rp = *reinterpret_cast<const float4*>(b.reps + i * b.DIM);   // rows of 4, 8 or 16 floats
+    bool far = false;
 
 #pragma unroll 1
     for (int v = 0; v < b.nviews; ++v) {
@@ -340,6 +342,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_batch_kernel(const P
                     bin.y = (uint32_t)(sp.rect.x1 - sp.rect.x0) | ((uint32_t)(sp.rect.y1 - sp.rect.y0) << 16);
                     bin.z = f2bits(sp.depth);
                     bin.w = tiles;
+                    far = far || bin.z >= DEPTH_KEY_FAR;
                 }
             }
             bv.radii[i] = radius;
@@ -355,6 +358,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_batch_kernel(const P
             s_vis[v][w] = wv;
         }
     }
+    if (__ballot(far) != 0 && lane == 0) atomicOr(b.far_flag, 1u);   // (practically never: depths beyond 13107)
     __syncthreads();
     if ((int)threadIdx.x < b.nviews) {
         const int v = threadIdx.x;
@@ -475,8 +479,10 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_batch_kernel(const S
 // Depth keys for ordering the Gaussians front to back: the f32 bits of the
 // view-space depth (positive floats order like their bit patterns), all ones
 // for Gaussians that produce no instance so that they sort to the end.
+// bias / none: subtracted from the depth bits / the key of a Gaussian without instances (0 and all ones for
+// keys on 32 bits, DEPTH_KEY_BIAS and 2^27 - 1 for the narrow keys).
 __device__ __forceinline__ void depth_keys_body(int P, const uint2* dt, const uint32_t* vis_off, uint32_t* keys,
-                                                uint32_t* vals) {
+                                                uint32_t* vals, uint32_t bias = 0u, uint32_t none = 0xFFFFFFFFu) {
     // vis_off == null: one pair per Gaussian (those without instances get the largest key).
     // Otherwise only Gaussians with instances get a pair, packed in index order: a block's pairs
     // start at vis_off[block] (blocks = the preprocess blocks that counted them).
@@ -485,7 +491,7 @@ __device__ __forceinline__ void depth_keys_body(int P, const uint2* dt, const ui
     const uint2 b = i < P ? dt[i] : make_uint2(0, 0);   // depth bits, tiles
     if (!vis_off) {
         if (i < P) {
-            keys[i] = b.y ? b.x : 0xFFFFFFFFu;
+            keys[i] = b.y ? b.x - bias : none;
             vals[i] = (uint32_t)i;
         }
         return;
@@ -498,7 +504,7 @@ __device__ __forceinline__ void depth_keys_body(int P, const uint2* dt, const ui
     for (int k = 0; k < w; ++k) base += s_w[k];
     if (b.y > 0) {
         const uint32_t dst = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        keys[dst] = b.x;
+        keys[dst] = b.x - bias;
         vals[dst] = (uint32_t)i;
     }
 }
@@ -509,6 +515,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) depth_keys_kernel(int P, const uint
 }
 
 struct DepthKeysBatch {   // blockIdx.y = view
+    uint32_t bias, none;
     const uint2* dt[SORT_BATCH_MAX];
     const uint32_t* vis_off[SORT_BATCH_MAX];
     uint32_t* keys[SORT_BATCH_MAX];
@@ -517,7 +524,7 @@ struct DepthKeysBatch {   // blockIdx.y = view
 
 __global__ void __launch_bounds__(PRE_BLOCK) depth_keys_batch_kernel(int P, const DepthKeysBatch b) {
     const int v = blockIdx.y;
-    depth_keys_body(P, b.dt[v], b.vis_off[v], b.keys[v], b.vals[v]);
+    depth_keys_body(P, b.dt[v], b.vis_off[v], b.keys[v], b.vals[v], b.bias, b.none);
 }
 
 // The tile rectangles in depth order: sbin[i] = {rect origin, rect size, Gaussian
@@ -836,8 +843,10 @@ hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, cons
     return hipGetLastError();
 }
 
-hipError_t launch_preprocess_fwd_batch(const GsrScene& s, int nviews, const GsrForwardView* views, hipStream_t st) {
+hipError_t launch_preprocess_fwd_batch(const GsrScene& s, int nviews, const GsrForwardView* views, uint32_t* far_flag,
+                                       hipStream_t st) {
     PreBatchArgs b;
+    b.far_flag = far_flag;
     b.P = s.P; b.D = s.D; b.M = s.M; b.DIM = s.DIM;
     b.mod = s.scale_modifier; b.raw = s.raw_params;
     b.means3D = s.means3D; b.shs = s.shs; b.shs_rest = s.shs_rest; b.opacities = s.opacities;
@@ -893,10 +902,13 @@ hipError_t launch_depth_order(const GeomBuf& g, int P, int n, hipStream_t st, in
     return launch_radix_sort_u32(k, v, n, 0, 32, g.dsort_temp, st, order_buffer, false);
 }
 
-hipError_t launch_depth_order_batch(int count, const GeomBuf* g, int P, const int* n, hipStream_t st) {
+hipError_t launch_depth_order_batch(int count, const GeomBuf* g, int P, const int* n, bool narrow, hipStream_t st) {
     if (count <= 0 || P <= 0) return hipSuccess;
     if (count > SORT_BATCH_MAX) return hipErrorInvalidValue;
     DepthKeysBatch b;
+    b.bias = narrow ? DEPTH_KEY_BIAS : 0u;
+    b.none = narrow ? (1u << SORT_NARROW_KEY_BITS) - 1u : 0xFFFFFFFFu;
+    const int first = narrow ? 1 : 0;   // three passes from buffer 1, four from buffer 0: the order ends in buffer 0
     uint32_t* keys[SORT_BATCH_MAX][2];
     uint32_t* vals[SORT_BATCH_MAX][2];
     int64_t n64[SORT_BATCH_MAX];
@@ -904,15 +916,15 @@ hipError_t launch_depth_order_batch(int count, const GeomBuf* g, int P, const in
     for (int i = 0; i < count; ++i) {
         b.dt[i] = g[i].dt;
         b.vis_off[i] = n[i] < P ? g[i].vis_sums : (const uint32_t*)nullptr;
-        b.keys[i] = g[i].dkeys[0];
-        b.vals[i] = g[i].dvals[0];
+        b.keys[i] = g[i].dkeys[first];
+        b.vals[i] = g[i].dvals[first];
         keys[i][0] = g[i].dkeys[0]; keys[i][1] = g[i].dkeys[1];
         vals[i][0] = g[i].dvals[0]; vals[i][1] = g[i].dvals[1];
         n64[i] = n[i];
         temp[i] = g[i].dsort_temp;
     }
     hipLaunchKernelGGL(depth_keys_batch_kernel, dim3((P + PRE_BLOCK - 1) / PRE_BLOCK, count), dim3(PRE_BLOCK), 0, st, P, b);
-    return launch_radix_sort_u32_batch(count, keys, vals, n64, temp, st);
+    return launch_radix_sort_u32_batch(count, keys, vals, n64, temp, st, narrow ? SORT_NARROW_KEY_BITS : 32);
 }
 
 hipError_t launch_order_gather(const GeomBuf& g, const uint32_t* order, int n, hipStream_t st) {

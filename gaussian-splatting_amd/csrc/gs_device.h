@@ -435,6 +435,14 @@ inline ImageView image_view(void* base, size_t W, size_t H) {
 constexpr int SORT_TILE = GS_SORT_TILE;   // keys per onesweep workgroup
 constexpr int SORT_MAX_PASSES = 8;
 constexpr int SORT_BATCH_MAX = 8;         // independent sorts that share the launches of launch_radix_sort_u32_batch
+// Depth keys: the f32 bits of a view-space depth above the near plane (0.2, auxiliary.h:154-168: a point
+// with depth <= 0.2 is culled) minus the bits of 0.2 stay below 2^27 while the depth is below 0.2 * 2^16
+// = 13107.2 (sixteen octaves of 2^23 codes each): three 9-bit radix passes order them instead of four 8-bit
+// ones over the raw bits.  A view with a Gaussian beyond that takes the four passes.
+constexpr int SORT_NARROW_KEY_BITS = 27;
+constexpr uint32_t DEPTH_KEY_BIAS = 0x3E4CCCCDu;                        // bits of 0.2f
+constexpr uint32_t DEPTH_KEY_FAR = DEPTH_KEY_BIAS + (1u << SORT_NARROW_KEY_BITS);   // bits of 13107.2f
+constexpr int SORT_BATCH_TEMP_PASSES = 6;  // status words of a batched sort: 4 passes x 256 or 3 x 512 per tile
 
 // The key bits are dealt evenly to the passes (13 bits: 7 + 6, not 8 + 5): the fewer buckets a
 // pass has, the longer the contiguous run a tile writes into each of them.

@@ -24,7 +24,9 @@ struct GeomBuf {
     uint32_t* vis_sums;   // [nblocks+1] Gaussians with instances per block, then exclusive offsets
     uint64_t* total;      // [4] instances, overflow flag, Gaussians with instances, "a point was culled although
                           // the caller declared them prefiltered"; then [3 * SCAN_BATCH_MAX]: the first
-                          // three of every view whose scans ran in one launch with this view as the first
+                          // three of every view whose scans ran in one launch with this view as the first;
+                          // then [1]: "a Gaussian of some view of the batch whose first view this is lies at
+                          // or beyond DEPTH_KEY_FAR" (zeroed and read by gsr_preprocess_batch)
     uint32_t* dkeys[2];   // [P] depth bits (all ones for Gaussians that are not rendered), ping-pong
     uint32_t* dvals[2];   // [P] Gaussian index, ping-pong; the sorted one is the front-to-back order
     uint4* sbin;          // [P] {x0 | y0<<16, w | h<<16, Gaussian index, tiles} in front-to-back order
@@ -47,14 +49,14 @@ inline GeomBuf geom_buf(const void* base, size_t P) {
     v.clamped = (uint8_t*)take(P);
     v.block_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));
     v.vis_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));
-    v.total = (uint64_t*)take((4 + 3 * SCAN_BATCH_MAX) * sizeof(uint64_t));
+    v.total = (uint64_t*)take((4 + 3 * SCAN_BATCH_MAX + 1) * sizeof(uint64_t));
     v.dkeys[0] = (uint32_t*)take(P * sizeof(uint32_t));
     v.dkeys[1] = (uint32_t*)take(P * sizeof(uint32_t));
     v.dvals[0] = (uint32_t*)take(P * sizeof(uint32_t));
     v.dvals[1] = (uint32_t*)take(P * sizeof(uint32_t));
     v.sbin = (uint4*)take(P * sizeof(uint4));
     v.order_sums = (uint32_t*)take((nb + 1) * sizeof(uint32_t));
-    v.dsort_temp = take(sort_temp_view(nullptr, P ? P : 1, 4).bytes);
+    v.dsort_temp = take(sort_temp_view(nullptr, P ? P : 1, SORT_BATCH_TEMP_PASSES).bytes);
     v.bytes = off;
     return v;
 }
@@ -86,7 +88,10 @@ void sort_set_force_wide(bool on);   // test hook: 64-bit look-back status words
 hipError_t launch_preprocess_fwd(const GsrScene& s, const GsrForwardOut& o, const GeomBuf& g, hipStream_t st);
 // The preprocess of several views in one pass over the Gaussians (everything launch_preprocess_fwd
 // leaves in a view's geometry buffer except the 3D covariance).
-hipError_t launch_preprocess_fwd_batch(const GsrScene& s, int nviews, const GsrForwardView* views, hipStream_t st);
+// far_flag (device word, zeroed by the caller): set when a Gaussian in front of some view's near plane has a
+// depth whose bits reach DEPTH_KEY_FAR.
+hipError_t launch_preprocess_fwd_batch(const GsrScene& s, int nviews, const GsrForwardView* views, uint32_t* far_flag,
+                                       hipStream_t st);
 // Exclusive scans of the per-block tile sums and visible counts; totals into g.total.
 hipError_t launch_scan_blocks(const GeomBuf& g, int nb, hipStream_t st);
 // The same for `count` views (at most SCAN_BATCH_MAX) in one launch; *all: device array of 3 totals per view.
@@ -95,8 +100,10 @@ hipError_t launch_scan_blocks_batch(int count, const GeomBuf* g, int nb, hipStre
 // sorted front to back (stable): g.dvals[*order_buffer][0..n) is the order.
 hipError_t launch_depth_order(const GeomBuf& g, int P, int n, hipStream_t st, int* order_buffer);
 // The same for up to SORT_BATCH_MAX views of the same P Gaussians in shared launches (n[i] as above, each
-// below 2^30); every view's order ends in its g.dvals[0].
-hipError_t launch_depth_order_batch(int count, const GeomBuf* g, int P, const int* n, hipStream_t st);
+// below 2^30); every view's order ends in its g.dvals[0].  narrow: every depth to order lies below
+// DEPTH_KEY_FAR, so the keys are the depth bits minus DEPTH_KEY_BIAS on 27 bits (three passes instead of four;
+// the same order).
+hipError_t launch_depth_order_batch(int count, const GeomBuf* g, int P, const int* n, bool narrow, hipStream_t st);
 // Key emission in depth order: (tile id, Gaussian index) pairs; only the tile remains to be sorted on.
 hipError_t launch_emit_keys(const GsrScene& s, const GeomBuf& g, const uint32_t* order, int n, uint32_t* keys,
                             uint32_t* vals, hipStream_t st);
@@ -150,7 +157,7 @@ hipError_t launch_segmented_pass(int n_visible, int ntiles, int nbits, int64_t R
                                  uint32_t* vals[2], void* temp, hipStream_t st, bool packed);
 // The same with 32-bit keys.  hist_ready: the digit histograms in the temp area were filled by the caller.
 hipError_t launch_radix_sort_u32_batch(int count, uint32_t* const (*keys)[2], uint32_t* const (*vals)[2], const int64_t* n,
-                                       void* const* temp, hipStream_t st);
+                                       void* const* temp, hipStream_t st, int key_bits);
 hipError_t launch_radix_sort_u32(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int begin_bit, int end_bit,
                                  void* temp, hipStream_t st, int* result_buffer, bool hist_ready);
 

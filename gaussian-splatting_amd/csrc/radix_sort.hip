@@ -49,18 +49,19 @@ int sort_passes_for(int begin_bit, int end_bit) { return (end_bit - begin_bit + 
 // Digit histograms of all passes in one read of the keys, 16 bytes per lane and load (a lane
 // that reads one key per trip spends its time waiting for that load).
 // (nblocks workgroups, numbered blockIdx.x = 0 .. nblocks - 1, share the keys)
-template <class K>
+// NBINS: bins per pass (256 for digits of up to 8 bits, 512 for 9-bit digits); passes * NBINS <= 2048.
+template <class K, int NBINS = 256>
 __device__ __forceinline__ void sort_hist_body(const K* keys, int64_t n, int passes, int begin_bit, int end_bit,
                                                uint32_t* ghist, int nblocks) {
     constexpr int V = 16 / sizeof(K);
     __shared__ uint32_t h[SORT_MAX_PASSES * 256];
-    for (int i = threadIdx.x; i < passes * 256; i += 256) h[i] = 0;
+    for (int i = threadIdx.x; i < passes * NBINS; i += 256) h[i] = 0;
     __syncthreads();
     int shift[SORT_MAX_PASSES], bits[SORT_MAX_PASSES];
     for (int p = 0; p < passes; ++p) digit_of_pass(end_bit - begin_bit, passes, p, &shift[p], &bits[p]);
     auto count = [&](K k) {
         for (int p = 0; p < passes; ++p)
-            atomicAdd(&h[p * 256 + ((uint32_t)(k >> (begin_bit + shift[p])) & ((1u << bits[p]) - 1))], 1u);
+            atomicAdd(&h[p * NBINS + ((uint32_t)(k >> (begin_bit + shift[p])) & ((1u << bits[p]) - 1))], 1u);
     };
     const int64_t stride = (int64_t)nblocks * 256;
     const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -78,18 +79,18 @@ __device__ __forceinline__ void sort_hist_body(const K* keys, int64_t n, int pas
             for (int e = 1; e < V; ++e) {
                 const uint32_t d = (uint32_t)(g.k[e] >> (begin_bit + shift[p])) & mask;
                 if (d != cur) {
-                    atomicAdd(&h[p * 256 + cur], c);
+                    atomicAdd(&h[p * NBINS + cur], c);
                     cur = d;
                     c = 0;
                 }
                 ++c;
             }
-            atomicAdd(&h[p * 256 + cur], c);
+            atomicAdd(&h[p * NBINS + cur], c);
         }
     }
     for (int64_t i = nvec * V + gtid; i < n; i += stride) count(keys[i]);
     __syncthreads();
-    for (int i = threadIdx.x; i < passes * 256; i += 256) {
+    for (int i = threadIdx.x; i < passes * NBINS; i += 256) {
         const uint32_t v = h[i];
         if (v) atomicAdd(&ghist[i], v);
     }
@@ -115,6 +116,7 @@ struct SortBatchArgs {
     uint32_t* err[SORT_BATCH_MAX];
 };
 
+template <int NBINS>
 __global__ void __launch_bounds__(256) sort_hist_batch_kernel(const SortBatchArgs b, int passes, int begin_bit,
                                                               int end_bit) {
     const int v = blockIdx.y;
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(256) sort_hist_batch_kernel(const SortBatchArg
     const int64_t tiles = (b.n[v] + SORT_TILE - 1) / SORT_TILE;
     const int nblocks = (int)(tiles < (int64_t)gridDim.x ? tiles : (int64_t)gridDim.x);
     if ((int)blockIdx.x >= nblocks) return;
-    sort_hist_body<uint32_t>(b.kin[v], b.n[v], passes, begin_bit, end_bit, b.ghist[v], nblocks);
+    sort_hist_body<uint32_t, NBINS>(b.kin[v], b.n[v], passes, begin_bit, end_bit, b.ghist[v], nblocks);
 }
 
 // Exclusive scan of each pass's 256-bin histogram, in place.
@@ -134,12 +136,33 @@ __global__ void __launch_bounds__(256) sort_scan_hist_kernel(uint32_t* ghist) {
     h[threadIdx.x] = ex;
 }
 
-__global__ void __launch_bounds__(256) sort_scan_hist_batch_kernel(const SortBatchArgs b) {
-    __shared__ uint32_t s_tmp[8];
+// Exclusive scan over all threads of a block of NW waves.
+template <int NW>
+__device__ __forceinline__ uint32_t block_scan_excl_nw(uint32_t v, uint32_t* tmp, uint32_t* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t incl = wave_scan_incl_u32(v);
+    if (lane == 63) tmp[w] = incl;
+    __syncthreads();
+    uint32_t base = 0, sum = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const uint32_t t = tmp[i];
+        if (i < w) base += t;
+        sum += t;
+    }
+    __syncthreads();
+    *total = sum;
+    return base + incl - v;
+}
+
+// NBINS threads: one per bin of the pass blockIdx.x
+template <int NBINS>
+__global__ void __launch_bounds__(NBINS) sort_scan_hist_batch_kernel(const SortBatchArgs b) {
+    __shared__ uint32_t s_tmp[NBINS / 64];
     if (b.n[blockIdx.y] <= 0) return;   // left out: no histogram
-    uint32_t* h = b.ghist[blockIdx.y] + blockIdx.x * 256;
+    uint32_t* h = b.ghist[blockIdx.y] + blockIdx.x * NBINS;
     uint32_t total;
-    const uint32_t ex = block_scan_excl_256(h[threadIdx.x], s_tmp, &total);
+    const uint32_t ex = block_scan_excl_nw<NBINS / 64>(h[threadIdx.x], s_tmp, &total);
     h[threadIdx.x] = ex;
 }
 
@@ -189,21 +212,23 @@ __device__ __forceinline__ void onesweep_tile(const K* __restrict__ kin, const u
     constexpr int NW = THREADS / 64;
     constexpr int TILE = THREADS * ITEMS;
     constexpr bool ONE_PHASE = sizeof(K) == 4;  // keys and values fit the staging area together
+    constexpr int NB = BITS > 8 ? 512 : 256;    // bins, and status words per tile
     static_assert(TILE == SORT_TILE, "tile size must match the status array layout");
+    static_assert(NB <= THREADS, "one thread per bin");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     K* s_keys = reinterpret_cast<K*>(smem);                               // [TILE]
     uint32_t* s_vals = reinterpret_cast<uint32_t*>(smem) + (ONE_PHASE ? TILE : 0);  // [TILE]; u64 keys: second phase
     // (packed instances are staged as keys only: the tables follow 4 bytes per pair, not 8)
-    uint32_t* s_whist = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * (PACKED ? 4 : 8));  // [NW][256]
-    uint32_t* s_hist = s_whist + NW * 256;                                // [256]
-    uint32_t* s_dstart = s_hist + 256;                                    // [256]
-    uint32_t* s_gofs = s_dstart + 256;                                    // [256]
-    uint32_t* s_tmp = s_gofs + 256;                                       // [8]
+    uint32_t* s_whist = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * (PACKED ? 4 : 8));  // [NW][NB]
+    uint32_t* s_hist = s_whist + NW * NB;                                 // [NB]
+    uint32_t* s_dstart = s_hist + NB;                                     // [NB]
+    uint32_t* s_gofs = s_dstart + NB;                                     // [NB]
+    uint32_t* s_tmp = s_gofs + NB;                                        // [8]
     uint32_t* s_tile = s_tmp + 8;                                         // [1]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) *s_tile = atomicAdd(ticket, 1u);
-    for (int i = tid; i < (NW + 1) * 256; i += THREADS) s_whist[i] = 0;  // counters and s_hist
+    for (int i = tid; i < (NW + 1) * NB; i += THREADS) s_whist[i] = 0;  // counters and s_hist
     __syncthreads();
     const uint32_t tile = *s_tile;
     int64_t tile_base = (int64_t)tile * TILE;
@@ -249,14 +274,16 @@ __device__ __forceinline__ void onesweep_tile(const K* __restrict__ kin, const u
         if ((wave_base + k * 64 + lane) < n) atomicAdd(&s_hist[(uint32_t)(key[k] >> shift) & dmask], 1u);
     }
     __syncthreads();
-    const bool dthread = tid < 256;  // threads that own a digit
+    const bool dthread = tid < NB;  // threads that own a digit
     const uint32_t dcount = dthread ? s_hist[tid] : 0u;
-    S* const my = status + (size_t)tile * 256 + tid;
+    S* const my = status + (size_t)tile * NB + tid;
     if (dthread)
         __hip_atomic_store(my, (S)dcount | (first_tile ? St<S>::INCL : St<S>::AGG), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     uint32_t tile_total;
-    const uint32_t dstart = block_scan_excl_256_nw<NW>(dcount, s_tmp, &tile_total);
+    uint32_t dstart;
+    if constexpr (NB == 256) dstart = block_scan_excl_256_nw<NW>(dcount, s_tmp, &tile_total);
+    else dstart = block_scan_excl_nw<NW>(dcount, s_tmp, &tile_total);
     if (dthread) s_dstart[tid] = dstart;
 
     // 2. Stable ranking inside the wave: lanes holding the same digit find each
@@ -267,7 +294,7 @@ __device__ __forceinline__ void onesweep_tile(const K* __restrict__ kin, const u
     //    Bits above `bits` are zero in every digit and change nothing, so the
     //    loop runs over the BITS the kernel was instantiated for without a test.
     typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
-    lds_u32* const wh = (lds_u32*)(s_whist + w * 256);
+    lds_u32* const wh = (lds_u32*)(s_whist + w * NB);
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
         const bool ok = (wave_base + k * 64 + lane) < n;
@@ -293,8 +320,8 @@ __device__ __forceinline__ void onesweep_tile(const K* __restrict__ kin, const u
         uint32_t run = 0;
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            const uint32_t c = s_whist[i * 256 + tid];
-            s_whist[i * 256 + tid] = run;
+            const uint32_t c = s_whist[i * NB + tid];
+            s_whist[i * NB + tid] = run;
             run += c;
         }
     }
@@ -311,7 +338,7 @@ __device__ __forceinline__ void onesweep_tile(const K* __restrict__ kin, const u
 #pragma unroll
                 for (int i = 0; i < LOOK_BATCH; ++i) {
                     const int64_t t = look - i;
-                    v[i] = t >= 0 ? __hip_atomic_load(status + (size_t)t * 256 + tid, __ATOMIC_RELAXED,
+                    v[i] = t >= 0 ? __hip_atomic_load(status + (size_t)t * NB + tid, __ATOMIC_RELAXED,
                                                       __HIP_MEMORY_SCOPE_AGENT)
                                   : St<S>::INCL;
                 }
@@ -354,7 +381,7 @@ __device__ __forceinline__ void onesweep_tile(const K* __restrict__ kin, const u
     for (int k = 0; k < ITEMS; ++k) {
         const bool ok = (wave_base + k * 64 + lane) < n;
         const uint32_t d = (uint32_t)(key[k] >> shift) & dmask;
-        rank[k] = s_dstart[d] + s_whist[w * 256 + d] + rank[k];  // slot inside the tile
+        rank[k] = s_dstart[d] + s_whist[w * NB + d] + rank[k];  // slot inside the tile
         if (ok) {
             s_keys[rank[k]] = key[k];
             if (ONE_PHASE && !PACKED) s_vals[rank[k]] = val[k];
@@ -409,13 +436,13 @@ onesweep_kernel(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* 
 
 // One pass of several independent sorts (see SortBatchArgs).  Exactly ceil(n / tile) workgroups of a sort
 // go on and take its tickets, so that its tile numbers stay inside its status words.
-template <int THREADS, int ITEMS>
+template <int THREADS, int ITEMS, int BITS>
 __global__ void __launch_bounds__(THREADS, (GS_OS_BLOCKS * THREADS) / 256)
 onesweep_batch_kernel(const SortBatchArgs b, int shift, int bits) {
     const int v = blockIdx.y;
     const int64_t n = b.n[v];
     if ((int64_t)blockIdx.x * (THREADS * ITEMS) >= n) return;
-    onesweep_tile<uint32_t, THREADS, ITEMS, 8, false, uint32_t>(b.kin[v], b.vin[v], b.kout[v], b.vout[v], n, shift, bits,
+    onesweep_tile<uint32_t, THREADS, ITEMS, BITS, false, uint32_t>(b.kin[v], b.vin[v], b.kout[v], b.vout[v], n, shift, bits,
                                                                  b.ghist[v], b.status[v], b.ticket[v], b.err[v], SegArgs());
 }
 
@@ -450,25 +477,6 @@ constexpr int EP_CHUNK = EP_THREADS * EP_ITEMS;  // instances per chunk
 constexpr int EP_MAX_BLOCKS = EP_CHUNK / 256 + 1;
 constexpr int EP_MAX_PER = (EP_MAX_BLOCKS * 256 + EP_THREADS - 1) / EP_THREADS;
 static_assert(EP_CHUNK >= 2048, "fused_sort_temp_bytes sizes the chunk tables for chunks of at least 2048");
-
-// Exclusive scan over all threads of a block of NW waves.
-template <int NW>
-__device__ __forceinline__ uint32_t block_scan_excl_nw(uint32_t v, uint32_t* tmp, uint32_t* total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t incl = wave_scan_incl_u32(v);
-    if (lane == 63) tmp[w] = incl;
-    __syncthreads();
-    uint32_t base = 0, sum = 0;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        const uint32_t t = tmp[i];
-        if (i < w) base += t;
-        sum += t;
-    }
-    __syncthreads();
-    *total = sum;
-    return base + incl - v;
-}
 
 struct EmitPartArgs {
     const uint4* sbin;            // [n] {x0 | y0<<16, w | h<<16, Gaussian index, tiles} in depth order
@@ -797,54 +805,67 @@ hipError_t radix_sort_impl(K* keys[2], uint32_t* vals[2], int64_t n, int begin_b
     return hipGetLastError();
 }
 
-// Up to SORT_BATCH_MAX stable sorts of u32 pairs on all 32 key bits, pass by pass in shared launches; every
-// result ends in keys[0] / vals[0] (four passes).  Arrays of at most 2^30 pairs; n[i] <= 0 leaves sort i out.
-hipError_t launch_radix_sort_u32_batch(int count, uint32_t* const (*keys)[2], uint32_t* const (*vals)[2], const int64_t* n,
-                                       void* const* temp, hipStream_t st) {
-    if (count <= 0) return hipSuccess;
-    if (count > SORT_BATCH_MAX) return hipErrorInvalidValue;
-    constexpr int passes = 4;
-    static_assert(passes % 2 == 0, "the result must end in buffer 0");
+// Up to SORT_BATCH_MAX stable sorts of u32 pairs, pass by pass in shared launches.  key_bits = 32: four passes
+// of 8-bit digits, the input in keys[i][0] / vals[i][0]; key_bits = 27 (SORT_NARROW_KEY_BITS; the caller
+// guarantees keys below 2^27): three passes of 9-bit digits with 512 bins and status words per tile, the input
+// in keys[i][1] / vals[i][1].  Either way every result ends in keys[i][0] / vals[i][0].  temp[i]: room for
+// sort_temp_view(n, SORT_BATCH_TEMP_PASSES).  Arrays of at most 2^30 pairs; n[i] <= 0 leaves sort i out.
+template <int NBINS, int BITS>
+static hipError_t radix_sort_u32_batch_impl(int count, uint32_t* const (*keys)[2], uint32_t* const (*vals)[2],
+                                            const int64_t* n, void* const* temp, hipStream_t st, int key_bits,
+                                            int passes) {
     SortBatchArgs b = SortBatchArgs();
     SortTemp t[SORT_BATCH_MAX];
     int64_t tiles[SORT_BATCH_MAX], max_tiles = 0;
+    int cur = passes & 1;   // an odd number of passes starts in buffer 1
     for (int i = 0; i < count; ++i) {
         b.n[i] = n[i] > 0 ? n[i] : 0;
         tiles[i] = (b.n[i] + SORT_TILE - 1) / SORT_TILE;
         if (tiles[i] == 0) continue;
         if (sort_status_wide((size_t)b.n[i])) return hipErrorInvalidValue;
-        t[i] = sort_temp_view(temp[i], (size_t)b.n[i], passes);
+        t[i] = sort_temp_view(temp[i], (size_t)b.n[i], SORT_BATCH_TEMP_PASSES);
         hipError_t e = hipMemsetAsync(t[i].ghist, 0, t[i].zero_bytes, st);
         if (e != hipSuccess) return e;
         if (tiles[i] > max_tiles) max_tiles = tiles[i];
-        b.kin[i] = keys[i][0];
+        b.kin[i] = keys[i][cur];
         b.ghist[i] = t[i].ghist;
     }
     if (max_tiles == 0) return hipSuccess;
     const unsigned hist_blocks = (unsigned)(max_tiles < 2048 ? max_tiles : 2048);
-    hipLaunchKernelGGL(sort_hist_batch_kernel, dim3(hist_blocks, count), dim3(256), 0, st, b, passes, 0, 32);
-    hipLaunchKernelGGL(sort_scan_hist_batch_kernel, dim3(passes, count), dim3(256), 0, st, b);
-    auto kern = onesweep_batch_kernel<OS_THREADS, OS_ITEMS>;
+    hipLaunchKernelGGL(sort_hist_batch_kernel<NBINS>, dim3(hist_blocks, count), dim3(256), 0, st, b, passes, 0, key_bits);
+    hipLaunchKernelGGL(sort_scan_hist_batch_kernel<NBINS>, dim3(passes, count), dim3(NBINS), 0, st, b);
+    auto kern = onesweep_batch_kernel<OS_THREADS, OS_ITEMS, BITS>;
+    constexpr size_t lds = (size_t)SORT_TILE * 8 + (OS_THREADS / 64 + 4) * NBINS * 4 + 64;
     hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)OS_LDS);
+                                        (int)lds);
     if (ea != hipSuccess) return ea;
-    int cur = 0;
     for (int p = 0; p < passes; ++p) {
         int shift, bits;
-        digit_of_pass(32, passes, p, &shift, &bits);
+        digit_of_pass(key_bits, passes, p, &shift, &bits);
         for (int i = 0; i < count; ++i) {
             if (tiles[i] == 0) continue;
             b.kin[i] = keys[i][cur]; b.vin[i] = vals[i][cur];
             b.kout[i] = keys[i][cur ^ 1]; b.vout[i] = vals[i][cur ^ 1];
-            b.ghist[i] = t[i].ghist + p * 256;
-            b.status[i] = (uint32_t*)t[i].status + (size_t)p * tiles[i] * 256;
+            b.ghist[i] = t[i].ghist + p * NBINS;
+            b.status[i] = (uint32_t*)t[i].status + (size_t)p * tiles[i] * NBINS;
             b.ticket[i] = t[i].ticket + p;
             b.err[i] = t[i].err;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)max_tiles, count), dim3(OS_THREADS), OS_LDS, st, b, shift, bits);
+        hipLaunchKernelGGL(kern, dim3((unsigned)max_tiles, count), dim3(OS_THREADS), lds, st, b, shift, bits);
         cur ^= 1;
     }
     return hipGetLastError();
+}
+
+hipError_t launch_radix_sort_u32_batch(int count, uint32_t* const (*keys)[2], uint32_t* const (*vals)[2], const int64_t* n,
+                                       void* const* temp, hipStream_t st, int key_bits) {
+    if (count <= 0) return hipSuccess;
+    if (count > SORT_BATCH_MAX) return hipErrorInvalidValue;
+    static_assert(3 * 512 <= SORT_BATCH_TEMP_PASSES * 256 && 4 * 256 <= SORT_BATCH_TEMP_PASSES * 256,
+                  "status words of either digit width must fit the temp area");
+    if (key_bits == SORT_NARROW_KEY_BITS) return radix_sort_u32_batch_impl<512, 9>(count, keys, vals, n, temp, st, 27, 3);
+    if (key_bits == 32) return radix_sort_u32_batch_impl<256, 8>(count, keys, vals, n, temp, st, 32, 4);
+    return hipErrorInvalidValue;
 }
 
 // ------------------------------------------------------------------ emission + segmented pass

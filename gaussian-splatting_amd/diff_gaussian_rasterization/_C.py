@@ -385,6 +385,7 @@ def preprocess_batch(means3D, opacities, scales, rotations, scale_modifier, sh, 
         for k, d in enumerate(out):
             d["num_rendered"], d["num_visible"] = int(arr[k].num_rendered), int(arr[k].num_visible)
             d["depth_ordered"] = bool(arr[k].depth_ordered)
+            d["depth_key_bits"] = {0: 0, 1: 32, 2: 27}[int(arr[k].depth_ordered)]   # which keys ordered it
     return out
 
 

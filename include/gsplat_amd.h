@@ -279,7 +279,9 @@ typedef struct {
     int depth_ordered;         /* out (host): nonzero = the call also ordered this view's Gaussians front to back (the
                                   depth sorts of up to eight views share their launches: a view's own sort is a
                                   single wave of workgroups waiting on its look-back chain); pass
-                                  GsrForwardOut.preprocessed = 2 to gsr_forward_stage2 then */
+                                  GsrForwardOut.preprocessed = 2 to gsr_forward_stage2 then.  The value says by
+                                  which keys: 2 = the depth bits minus the near plane's on 27 bits (three radix
+                                  passes; every depth of the batch below 13107.2), 1 = all 32 depth bits (four) */
 } GsrForwardView;
 int gsr_preprocess_batch(const GsrScene* scene, int nviews, GsrForwardView* views, void* stream);
 
@@ -463,6 +465,12 @@ void gsr_test_forward_reach_masks(int mode);
  * whenever the tile ids have two digits and the number of Gaussians fits below the digit (2^25 Gaussians
  * at 1080p, 2^24 at 4K); the sorted tile ids are then not stored.  Off: always as a (tile id, index) pair. */
 void gsr_test_packed_instances(int on);
+
+/* Test hook: the keys gsr_preprocess_batch orders each view's Gaussians by.  Off (the default): when every
+ * depth of the batch lies below 0.2 * 2^16 = 13107.2, the depth bits minus the bits of the near plane's 0.2,
+ * on 27 bits in three radix passes; the raw 32 depth bits in four passes otherwise.  On: always the latter.
+ * The order is the same either way. */
+void gsr_test_wide_depth_keys(int on);
 
 /* Test hook: while set, every gsr_forward_stage2 sets a sort's error word as a tripped look-back would:
  * 1 the instance sort's (binning buffer), 2 the depth order's (geometry buffer); 0 off. */

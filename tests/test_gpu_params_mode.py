@@ -304,12 +304,23 @@ def _arc_settings(nviews, W, H, aa=True, debug=True):
 
 
 @pytest.mark.parametrize("nviews,P", [(1, 300), (3, 500), (11, 777)])
-def test_batched_forward_preprocess_is_bit_identical(nviews, P):
+@pytest.mark.parametrize("depth_keys", ["narrow", "forced_wide", "far_gaussian"])
+def test_batched_forward_preprocess_is_bit_identical(nviews, P, depth_keys):
     """gsr_preprocess_batch + stage 1/2 with `preprocessed` set leaves every output and every
-    scratch array that later stages read exactly as the one-view preprocess does."""
+    scratch array that later stages read exactly as the one-view preprocess does.  The batch call orders the
+    Gaussians by 27-bit keys in three passes when every depth allows it (narrow), by all 32 depth bits in four
+    passes when told to (test hook) or when a Gaussian lies beyond 13107.2 (far_gaussian); the one-view path
+    always takes the 32 bits: the sorted lists must agree in all three cases."""
+    from _gsplat_lib import lib
     from diff_gaussian_rasterization import _C
     W, H = 96, 64
     sc = synth.tiny_scene(P=P, width=W, height=H, seed=31)
+    if depth_keys == "far_gaussian":
+        # a huge Gaussian far behind the scene, on camera 0's axis (the arc cameras look at (0, 0, 1))
+        cam0 = np.asarray(_arc_settings(nviews, W, H)[0].campos.cpu(), dtype=np.float64)
+        axis = np.array([0.0, 0.0, 1.0]) - cam0
+        sc["means3D"][3] = cam0 + axis / np.linalg.norm(axis) * 20000.0
+        sc["scales"][3] = 400.0
     raw = _raw_scene(sc, seed=5)
     settings = _arc_settings(nviews, W, H)
     t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda:0")
@@ -325,9 +336,15 @@ def test_batched_forward_preprocess_is_bit_identical(nviews, P):
             rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, ten["dc"], rs.sh_degree, rs.campos,
             False, rs.antialiasing, rs.debug, ten["reps"], sh_rest=ten["rest"], raw_params=True, prepared=prepared)))
 
-    prep = _C.preprocess_batch(ten["xyz"], ten["opacity"], ten["scaling"], ten["rotation"], 1.0, ten["dc"], ten["rest"], 3,
-                               ten["reps"], True, settings, debug=True)
+    lib().gsr_test_wide_depth_keys(1 if depth_keys == "forced_wide" else 0)
+    try:
+        prep = _C.preprocess_batch(ten["xyz"], ten["opacity"], ten["scaling"], ten["rotation"], 1.0, ten["dc"], ten["rest"],
+                                   3, ten["reps"], True, settings, debug=True)
+    finally:
+        lib().gsr_test_wide_depth_keys(0)
     assert len(prep) == nviews
+    bits = {pr["depth_key_bits"] for pr in prep if pr["depth_ordered"]}
+    assert bits == ({27} if depth_keys == "narrow" else {32}), bits
     seen_any = 0
     for rs, pr in zip(settings, prep):
         a = fwd(rs, None)
