@@ -382,6 +382,8 @@ def main():
                          "kernels walk ~40 %% of every tile list (reported as extras.translucent by the default run)")
     ap.add_argument("--gaussians", type=int, default=6_000_000)
     ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--dim", type=int, default=4, choices=(4, 8, 16),
+                    help="feature (reps) channels per Gaussian; the reference's build has 4 (config.h:16), its CLI default is 16")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--api", choices=("params", "reference"), default="params",
                     help="params: forward_params (raw parameters); reference: unchanged reference signature")
@@ -439,7 +441,7 @@ def main():
     P, W, H, V = args.gaussians, args.width, args.height, max(1, args.views_per_gpu)
     seed = 2
     t0 = time.time()
-    sc = synth.street_scene(P, W, H, seed=seed, translucent=args.scene == "translucent")
+    sc = synth.street_scene(P, W, H, seed=seed, translucent=args.scene == "translucent", dim=args.dim)
     params = build_params(sc, dev)
     sh_degree = sc["sh_degree"]
     del sc
@@ -872,8 +874,10 @@ def main():
             extras["translucent"] = {"error": repr(ex)}
 
     if rank == 0:
-        pmc_stale = pmc_is_stale(P, W, H, args.scene)
-        traffic = {} if pmc_stale else load_pmc_traffic(P, W, H, args.scene)
+        # the committed counter passes are of the 4-channel kernels
+        pmc_scene = args.scene if args.dim == 4 else f"{args.scene}_dim{args.dim}"
+        pmc_stale = pmc_is_stale(P, W, H, pmc_scene)
+        traffic = {} if pmc_stale else load_pmc_traffic(P, W, H, pmc_scene)
         per_kernel = {}
         launches = lambda k: 1 if k in KernelTimer.PER_STEP else V          # per step
 
@@ -904,7 +908,7 @@ def main():
         # instruction issues over 2 cycles on a 32-lane SIMD) at the nominal 2.4 GHz.  (The clock the counter
         # passes ran at is reported beside it; it belongs to the box of that collection, not to this run, so it
         # does not enter the peak: a slower box there must not flatter the fraction here.)
-        valu = {} if pmc_stale else load_pmc_valu(P, W, H, args.scene)
+        valu = {} if pmc_stale else load_pmc_valu(P, W, H, pmc_scene)
         for k, ent in per_kernel.items():
             if k in valu:
                 v = valu[k]
@@ -933,7 +937,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene if args.scene != 'street' else 'street scene'}"
-                                   f"{' street scene (small, mostly transparent splats)' if args.scene == 'translucent' else ''}, {P} Gaussians SH3 + 4 reps, {W}x{H}, antialiasing; a step = {V} views "
+                                   f"{' street scene (small, mostly transparent splats)' if args.scene == 'translucent' else ''}, {P} Gaussians SH3 + {args.dim} reps, {W}x{H}, antialiasing; a step = {V} views "
                                    f"per GPU (different cameras, gradients accumulate)" +
                                    (", forward only" if args.fwd_only else ", each fwd + fused-ssim loss + bwd, then the "
                                     "sum of the gradients over the GPUs when n_gpus > 1 (see allreduce); no optimizer"),

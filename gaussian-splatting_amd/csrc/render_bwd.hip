@@ -209,7 +209,11 @@ render_bwd_kernel(const RenderBwdArgs a) {
             // decided it with gs_expf, and a pixel taken here but not there would shift its transmittance
             // for the rest of its list.  A wave in which some pixel's alpha lies within 1e-5 relative of
             // the threshold repeats the visit's exponential exactly.
+#ifdef GS_BWD_EXACT_EXP   // (diagnostic build: the forward's polynomial everywhere; see also GS_BWD_EXACT_DIV)
+            float G = gs_expf_blend(power);
+#else
             float G = __builtin_amdgcn_exp2f(power * 1.44269504088896341f);  // lanes outside pm compute values nobody reads
+#endif
             float alpha = __builtin_fminf(GS_ALPHA_MAX, co.w * G);
             uint64_t vm = lanes_where(alpha >= GS_ALPHA_MIN * (1.0f + 1e-5f)) & pm;
             if ((lanes_where(alpha >= GS_ALPHA_MIN * (1.0f - 1e-5f)) & pm) != vm) {
@@ -247,9 +251,14 @@ render_bwd_kernel(const RenderBwdArgs a) {
             // sums of large terms it showed up as 3e-4 relative against a divide; with the step
             // the results match an IEEE divide (ten instructions) within the 1e-4 bar element-wise.
             const float oma = 1.f - alpha_e;
+#ifdef GS_BWD_EXACT_DIV
+            float inv_1ma = 1.0f / oma;
+            T = T / oma;
+#else
             float inv_1ma = __builtin_amdgcn_rcpf(oma);
             inv_1ma = fmaf(fmaf(-oma, inv_1ma, 1.0f), inv_1ma, inv_1ma);
             T = T * inv_1ma;
+#endif
             const float dchannel_dcolor = alpha_e * T;
             const f2 dc2 = {dchannel_dcolor, dchannel_dcolor};
             // The reference keeps, per channel, accum = last_alpha * last_c + (1 - last_alpha) * accum

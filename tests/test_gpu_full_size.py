@@ -146,7 +146,7 @@ def test_c2_translucent_render_2p5M_1080p_deep_lists(oracle):
         lib().gsr_test_packed_instances(1)
 
 
-def _c3_train_step(oracle, sc, tag):
+def _c3_train_step(oracle, sc, tag, floor=1e-2):
     t0 = time.time()
     f, out, rs, ten, kw_g = _check_forward(oracle, sc, True, (0.0, 0.0, 0.0))
     t1 = time.time()
@@ -170,13 +170,15 @@ def _c3_train_step(oracle, sc, tag):
     t2 = time.time()
     got = _grads_gpu(rs, ten, gc, None, gr, kw_g, out)
     torch.cuda.synchronize()
+    errs = {k: rel_err(got[k], ref[k].reshape(got[k].shape), floor) for k in got}
+    frac, per_tile = _walked_fraction(f, W, H)
+    print(f"{tag}: R={f.R}, walked {frac:.2f} of R (deepest {int(per_tile.max())}), forward {t1 - t0:.1f}s, "
+          f"backward {t2 - t1:.1f}s; largest element-wise gradient errors: "
+          + ", ".join(f"{k} {e:.1e}" for k, e in errs.items()))
     for k in got:
         r = ref[k].reshape(got[k].shape)
         assert np.isfinite(got[k]).all(), k
-        assert rel_err(got[k], r) <= REL_TOL, (k, rel_err(got[k], r), worst(got[k], r))
-    frac, per_tile = _walked_fraction(f, W, H)
-    print(f"{tag}: R={f.R}, walked {frac:.2f} of R (deepest {int(per_tile.max())}), forward {t1 - t0:.1f}s, "
-          f"backward {t2 - t1:.1f}s")
+        assert errs[k] <= REL_TOL, (k, errs[k], worst(got[k], r, floor))
     return f, frac, per_tile
 
 
@@ -193,6 +195,29 @@ def test_c3_translucent_train_step_6M_1297x840_deep_lists(oracle):
     f, frac, per_tile = _c3_train_step(oracle, sc, "C3t")
     assert f.R < 6 * int((f.radii > 0).sum())        # forward: the reach-mask kernel
     assert frac > 0.25 and int(per_tile.max()) > 1000
+
+
+def test_wide_feature_rows_train_step_2p5M_1297x840_dim16_deep_lists(oracle):
+    """Feature rows of 16 channels (the reference's CLI default, arguments/__init__.py:98; its kernels are
+    compiled for one width, config.h:16) at size, on the translucent scene where most visits blend (94 % of
+    the list entries walked, the deepest tile walk 5243 entries): the twelve extra channels are staged from the
+    caller's tensor per list entry in the forward and reduced into a second gradient record per Gaussian in
+    the backward.
+
+    The bar for the gradients here is |got - ref| <= 1e-4 |ref| + 3e-6 max|ref| per element (3e-6 instead of
+    the usual 1e-6 of the tensor's maximum for elements far below it).  Measured on scenes of this shape
+    (seeds 3, 4, 5; 2.5 M and 6 M Gaussians): with 4 channels the largest deviation under the usual measure is
+    3e-5 to 5e-5, with 16 channels 4e-5 to 1.1e-4, in a different tensor each time (dL_dmean3D once, dL_drot
+    once: single elements of a few thousandths of their tensor's maximum, off by 1.5e-6 of that maximum).
+    dL/dalpha of a pixel is a sum over the channels, 20 terms of mixed sign instead of 8, formed here as
+    S - accum_S from channel sums and in the checker channel by channel; both are float evaluations of the same
+    expression, and the geometry gradients are sums over pixels in which those terms cancel again.  The
+    kernel's shortcuts are not the cause: built with an IEEE division for T / (1 - alpha) and the polynomial
+    exponential (-DGS_BWD_EXACT_DIV -DGS_BWD_EXACT_EXP) the same elements deviate by the same amounts."""
+    sc = synth.street_scene(2_500_000, 1297, 840, seed=4, dim=16, translucent=True)
+    assert sc["reps"].shape == (2_500_000, 16)
+    f, frac, per_tile = _c3_train_step(oracle, sc, "C3 dim 16", floor=3e-2)
+    assert frac > 0.25
 
 
 def test_c4_multi_view_step_6M_1080p(oracle):
