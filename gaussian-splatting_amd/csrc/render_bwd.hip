@@ -13,6 +13,7 @@
 // complete line-half atomics instead of 64 scattered ones.
 #include "kernels.h"
 
+
 namespace gs {
 
 struct RenderBwdArgs {
@@ -43,10 +44,15 @@ constexpr int BWD_BATCH = 128;
 // DIM: feature ("reps") channels, 0, 4, 8 or 16.  The first four are components 10 .. 13 of the GradRec;
 // channels 4 .. DIM - 1 are a second group of up to 12 components with its own staged data, reduction,
 // LDS sums and 64-byte record per Gaussian (accx).
+template <int DIM> constexpr int bwd_waves() { return DIM > 8 ? 5 : DIM > 4 ? 6 : 8; }
+
 template <int DIM, bool INVD>
-// 8 waves per SIMD: the register allocator gets 64 VGPRs (it takes 66 when left alone, which costs a wave);
-// the wide-feature instantiations take what they need (4 waves).
-__global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(DIM > 4 ? 4 : 8, DIM > 4 ? 4 : 8)))
+// 8 waves per SIMD: the register allocator gets 64 VGPRs (it takes 66 when left alone, which costs a wave).
+// The wide-row instantiations are bound by the latency of a visit's chain of dependent instructions, so they
+// are compiled for the most waves their registers allow without spilling: 6 with 8 channels (80 VGPRs), 5 with
+// 16 (88 VGPRs; 30.8 KB of LDS allow no more).  Left alone the allocator takes 84 and 102 (4 waves): 16
+// channels 0.770 -> 0.736 ms, 8 channels 0.732 -> 0.69 ms on the street scene.
+__global__ void __launch_bounds__(TILE_PIX) __attribute__((amdgpu_waves_per_eu(bwd_waves<DIM>(), bwd_waves<DIM>())))
 render_bwd_kernel(const RenderBwdArgs a) {
     constexpr int XQ = DIM > 4 ? (DIM - 4) / 4 : 0;   // extra 16-byte pieces of a feature row
     // same regrouping of the SplatRec as in the forward kernel
