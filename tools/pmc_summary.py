@@ -49,7 +49,7 @@ COMPOSED = {
     "emit_keys": (("depth_order:gather", 1), ("emit_keys", 1)),
     # per step: the depth orders of all its views in shared launches
     "depth_order_batch": (("depth_order_batch:keys", 1), ("depth_order_batch:hist", 1), ("depth_order_batch:scan", 1),
-                          ("depth_order_batch:onesweep", 4)),
+                          ("depth_order_batch:onesweep", 3)),   # 27-bit keys: three passes (four if a depth reaches 13107.2)
 }
 
 
