@@ -18,7 +18,10 @@
 
 namespace gs {
 
-constexpr int KNN_BOX = 1024;
+#ifndef GS_KNN_BOX
+#define GS_KNN_BOX 1024
+#endif
+constexpr int KNN_BOX = GS_KNN_BOX;   // (a multiple of the 256 points of a workgroup: a wave lies inside one box)
 constexpr int KNN_SUPER = 32;  // boxes per super box
 
 struct KnnTemp {
@@ -204,11 +207,23 @@ __global__ void __launch_bounds__(256) knn_search_kernel(int P, const float4* __
 
     const int nb = (P + KNN_BOX - 1) / KNN_BOX;
     const int nsb = (nb + KNN_SUPER - 1) / KNN_SUPER;
+    // The wave's own box first (its 64 points are consecutive in Morton order and lie in one box): after it
+    // the third-nearest distance so far is close to the final one, and the box tests below reject with that
+    // instead of the distance among the six Morton neighbours.  The result does not depend on the order.
+    const int own = (blockIdx.x * 256 + (threadIdx.x & ~63)) / KNN_BOX;
+    {
+        const int jend = min(P, (own + 1) * KNN_BOX);
+        for (int j = own * KNN_BOX; j < jend; ++j) {
+            const float4 o = sorted[j];
+            if (live && j != idx) knn3_update(p, v3(o.x, o.y, o.z), best);
+        }
+    }
     for (int sb = 0; sb < nsb; ++sb) {
         const float ds = box_point_dist2(supers[sb], p);
         if (__ballot(!(ds > reject || ds > best[2])) == 0) continue;
         const int bend = min(nb, (sb + 1) * KNN_SUPER);
         for (int b = sb * KNN_SUPER; b < bend; ++b) {
+            if (b == own) continue;
             const float d = box_point_dist2(boxes[b], p);
             const bool want = !(d > reject || d > best[2]);
             if (__ballot(want) == 0) continue;
