@@ -715,9 +715,13 @@ GS_HD float box_point_dist2(const Box& b, V3 p) {
 }
 
 // simple_knn.cu:132-146 with K = 3
-GS_HD void knn3_update(V3 ref, V3 pt, float* best) {
+// (the squared distance with fused multiply-adds, as the reference's compiler contracts the expression)
+GS_HD float knn_dist2(V3 ref, V3 pt) {
     const V3 d = sub(pt, ref);
-    float dist = d.x * d.x + d.y * d.y + d.z * d.z;
+    return fmaf(d.z, d.z, fmaf(d.y, d.y, d.x * d.x));
+}
+GS_HD void knn3_update(V3 ref, V3 pt, float* best) {
+    float dist = knn_dist2(ref, pt);
     for (int j = 0; j < 3; j++) {
         if (best[j] > dist) {
             const float t = best[j];

@@ -186,6 +186,21 @@ __global__ void __launch_bounds__(256) knn_super_kernel(int nb, const Box* boxes
     supers[sb] = u;
 }
 
+// knn3_update (gs_math.h) as a network of minima and maxima: the three smallest of best[0] <= best[1] <=
+// best[2] and dist, five full-rate instructions instead of three compare-and-swap steps with selects.
+__device__ __forceinline__ void knn3_insert(float dist, float* best) {
+    const float r0 = __builtin_fmaxf(best[0], dist);
+    best[0] = __builtin_fminf(best[0], dist);
+    const float r1 = __builtin_fmaxf(best[1], r0);
+    best[1] = __builtin_fminf(best[1], r0);
+    best[2] = __builtin_fminf(best[2], r1);
+}
+__device__ __forceinline__ float knn_dist2(V3 ref, float4 o) { return knn_dist2(ref, v3(o.x, o.y, o.z)); }
+
+#ifdef GS_KNN_STATS
+static __device__ unsigned long long g_knn_stats[8];
+extern "C" void gsk_debug_stats(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_stats), sizeof(g_knn_stats)); }
+#endif
 // simple_knn.cu:148-184
 __global__ void __launch_bounds__(256) knn_search_kernel(int P, const float4* __restrict__ sorted,
                                                          const Box* __restrict__ boxes,
@@ -211,11 +226,15 @@ __global__ void __launch_bounds__(256) knn_search_kernel(int P, const float4* __
     // the third-nearest distance so far is close to the final one, and the box tests below reject with that
     // instead of the distance among the six Morton neighbours.  The result does not depend on the order.
     const int own = (blockIdx.x * 256 + (threadIdx.x & ~63)) / KNN_BOX;
+    // (No lane is masked in these loops: a candidate a lane did not ask for can only be one of its true
+    // neighbours or lose against them, and the lanes past P throw their result away.  Only the point itself
+    // has to be kept out, and it lies in the own box.)
     {
         const int jend = min(P, (own + 1) * KNN_BOX);
+#pragma unroll 4
         for (int j = own * KNN_BOX; j < jend; ++j) {
-            const float4 o = sorted[j];
-            if (live && j != idx) knn3_update(p, v3(o.x, o.y, o.z), best);
+            const float d2 = knn_dist2(p, sorted[j]);
+            knn3_insert(j == idx ? FLT_MAX : d2, best);
         }
     }
     for (int sb = 0; sb < nsb; ++sb) {
@@ -227,11 +246,32 @@ __global__ void __launch_bounds__(256) knn_search_kernel(int P, const float4* __
             const float d = box_point_dist2(boxes[b], p);
             const bool want = !(d > reject || d > best[2]);
             if (__ballot(want) == 0) continue;
-            const int jend = min(P, (b + 1) * KNN_BOX);
-            for (int j = b * KNN_BOX; j < jend; ++j) {
-                const float4 o = sorted[j];
-                if (want && j != idx) knn3_update(p, v3(o.x, o.y, o.z), best);
+#ifdef GS_KNN_STATS
+            {
+                const int nwant = __popcll(__ballot(want));
+                if ((threadIdx.x & 63) == 0) {
+                    atomicAdd(&g_knn_stats[0], 1ull);                       // box visits
+                    atomicAdd(&g_knn_stats[1], (unsigned long long)nwant);  // lanes that wanted
+                    if (nwant <= 4) atomicAdd(&g_knn_stats[2], 1ull);       // visits for <= 4 lanes
+                    if (nwant <= 16) atomicAdd(&g_knn_stats[3], 1ull);
+                }
             }
+#endif
+            const int jend = min(P, (b + 1) * KNN_BOX);
+            // four candidates at a time; the insertions are skipped when none of them comes closer than any
+            // lane's third-nearest so far, which after the own box is the usual case
+            int j = b * KNN_BOX;
+            for (; j + 4 <= jend; j += 4) {
+                const float d0 = knn_dist2(p, sorted[j]), d1 = knn_dist2(p, sorted[j + 1]);
+                const float d2 = knn_dist2(p, sorted[j + 2]), d3 = knn_dist2(p, sorted[j + 3]);
+                const float m = __builtin_fminf(__builtin_fminf(d0, d1), __builtin_fminf(d2, d3));
+                if (__ballot(m < best[2]) == 0) continue;
+                knn3_insert(d0, best);
+                knn3_insert(d1, best);
+                knn3_insert(d2, best);
+                knn3_insert(d3, best);
+            }
+            for (; j < jend; ++j) knn3_insert(knn_dist2(p, sorted[j]), best);
         }
     }
     if (live) dists[__float_as_uint(me.w)] = (best[0] + best[1] + best[2]) / 3.0f;
