@@ -159,13 +159,14 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
         // ... and when every Gaussian index fits beside the low digit in 32 bits, an instance is one word
         // between the two kernels instead of a (tile id, index) pair
         const bool packed = fused && fused_sort_packs(s->P, nbits) && t_packed_sort;
+        uint32_t *fused_ghist = nullptr, *fused_seg_start = nullptr, *fused_seg_tile0 = nullptr;
+        int lowshift = 0, lowbits = 0;
         if (fused) {
-            uint32_t *ghist, *seg_start, *seg_tile0;
-            int lowshift, lowbits;
             digit_of_pass(nbits, 2, 0, &lowshift, &lowbits);
-            GSR_TRY(fused_sort_prepare(b.sort_temp, R, n, nbits, st, &ghist, &seg_start, &seg_tile0));
-            GSR_TRY(launch_tile_ranges_from_rects(g, s->P, s->W, s->H, im, ghist, passes, nbits, st, lowbits, seg_start,
-                                                  seg_tile0));
+            GSR_TRY(fused_sort_prepare(b.sort_temp, R, n, nbits, st, &fused_ghist, &fused_seg_start, &fused_seg_tile0));
+            // the corner counts now; the ranges and segment tables in one launch with the instance offsets, behind
+            // the ordered rectangle gather below (two one-workgroup steps side by side)
+            GSR_TRY(launch_tile_count(g, s->P, s->W, s->H, im, st));
         } else if (from_rects) {
             hipError_t e = hipSuccess;
             uint32_t* ghist = sort_prepare(b.sort_temp, R, passes, st, &e);
@@ -180,7 +181,13 @@ int gsr_forward_stage2(const GsrScene* s, const GsrForwardOut* o, int64_t R, voi
             mark(s, GSR_EV_DEPTH_ORDER, st);
             if (fused) {
                 GSR_TRY(launch_order_gather(g, g.dvals[ord], n, st));
-                GSR_TRY(launch_emit_partition(g, n, (s->W + TILE_X - 1) / TILE_X, nbits, R, b.keys, b.vals, b.sort_temp, st, packed));
+                uint2* chunk_first = nullptr;
+                uint32_t chunks = 0;
+                fused_chunk_table(b.sort_temp, R, n, nbits, &chunk_first, &chunks);
+                GSR_TRY(launch_tile_finish_offsets(g, n, s->W, s->H, im, fused_ghist, passes, nbits, lowbits, fused_seg_start,
+                                                   fused_seg_tile0, chunk_first, chunks, st));
+                GSR_TRY(launch_emit_partition(g, n, (s->W + TILE_X - 1) / TILE_X, nbits, R, b.keys, b.vals, b.sort_temp, st,
+                                              packed, true));
                 mark(s, GSR_EV_EMIT, st);
                 GSR_TRY(launch_segmented_pass(n, ntiles, nbits, R, im.ranges, b.keys, b.vals, b.sort_temp, st, packed));
                 res = 0;

@@ -375,10 +375,10 @@ constexpr int SCAN_THREADS = 1024, SCAN_ITEMS = 32;
 // Workgroup 1, if launched, scans a second array the same way (the per-block
 // counts of Gaussians with instances) and writes its total into total[2].
 // `all`, if given: the three totals once more, where the totals of several views are collected.
-__device__ __forceinline__ void scan_blocks_body(uint32_t* sums0, uint32_t* sums1, int nb, uint64_t* total,
-                                                 uint64_t* all) {
+// (primary: the array of tile sums, whose total goes to total[0..1]; otherwise total[2])
+__device__ __forceinline__ void scan_blocks_one(uint32_t* block_sums, bool primary, int nb, uint64_t* total,
+                                                uint64_t* all) {
     __shared__ uint64_t s_wave[SCAN_THREADS / 64];
-    uint32_t* block_sums = blockIdx.x == 0 ? sums0 : sums1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     uint64_t carry = 0;
     for (int base = 0; base < nb; base += SCAN_THREADS * SCAN_ITEMS) {
@@ -444,7 +444,7 @@ __device__ __forceinline__ void scan_blocks_body(uint32_t* sums0, uint32_t* sums
     }
     if (tid == 0) {
         block_sums[nb] = (uint32_t)carry;
-        if (blockIdx.x == 0) {
+        if (primary) {
             total[0] = carry;
             total[1] = carry > 0x7fffffffull ? 1 : 0;
             if (all) {
@@ -456,6 +456,11 @@ __device__ __forceinline__ void scan_blocks_body(uint32_t* sums0, uint32_t* sums
             if (all) all[2] = carry;
         }
     }
+}
+
+__device__ __forceinline__ void scan_blocks_body(uint32_t* sums0, uint32_t* sums1, int nb, uint64_t* total,
+                                                 uint64_t* all) {
+    scan_blocks_one(blockIdx.x == 0 ? sums0 : sums1, blockIdx.x == 0, nb, total, all);
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* sums0, uint32_t* sums1, int nb,
@@ -497,10 +502,10 @@ __device__ __forceinline__ void depth_keys_body(int P, const uint2* dt, const ui
         return;
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t base = vis_off[blockIdx.x];   // (in flight during the ballot and the barrier)
     const uint64_t m = __ballot(b.y > 0);
     if (lane == 0) s_w[w] = (uint32_t)__popcll(m);
     __syncthreads();
-    uint32_t base = vis_off[blockIdx.x];
     for (int k = 0; k < w; ++k) base += s_w[k];
     if (b.y > 0) {
         const uint32_t dst = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
@@ -647,11 +652,11 @@ __global__ void __launch_bounds__(TC_THREADS) tile_count_kernel(int P, const uin
 // whose ranges are zero-filled and written only where the sorted keys change.
 // With seg_start: also where the instances of each value of the high digit (tile id >> lowbits, a
 // "segment") start, and the first sort-pass tile of each segment when no tile straddles two.
-__global__ void __launch_bounds__(TF_THREADS) tile_finish_kernel(int gx, int gy, const int* __restrict__ diff,
-                                                                 uint2* __restrict__ ranges, uint32_t* __restrict__ ghist,
-                                                                 int passes, int nbits, int lowbits, int nseg,
-                                                                 uint32_t* __restrict__ seg_start,
-                                                                 uint32_t* __restrict__ seg_tile0) {
+__device__ __forceinline__ void tile_finish_body(int gx, int gy, const int* __restrict__ diff,
+                                                 uint2* __restrict__ ranges, uint32_t* __restrict__ ghist,
+                                                 int passes, int nbits, int lowbits, int nseg,
+                                                 uint32_t* __restrict__ seg_start,
+                                                 uint32_t* __restrict__ seg_tile0) {
     extern __shared__ int s_all[];
     const int pitch = gx + 1, nd = pitch * (gy + 1), ntiles = gx * gy;
     int* s_c = s_all;                                                  // [nd] marks, then cover counts
@@ -740,6 +745,67 @@ __global__ void __launch_bounds__(TF_THREADS) tile_finish_kernel(int gx, int gy,
         seg_start[h] = s_seg[h];
         seg_tile0[h] = s_t0[h];
     }
+}
+
+__global__ void __launch_bounds__(TF_THREADS) tile_finish_kernel(int gx, int gy, const int* __restrict__ diff,
+                                                                 uint2* __restrict__ ranges, uint32_t* __restrict__ ghist,
+                                                                 int passes, int nbits, int lowbits, int nseg,
+                                                                 uint32_t* __restrict__ seg_start,
+                                                                 uint32_t* __restrict__ seg_tile0) {
+    tile_finish_body(gx, gy, diff, ranges, ghist, passes, nbits, lowbits, nseg, seg_start, seg_tile0);
+}
+
+// The two one-workgroup steps in front of the key emission that partitions, side by side in one launch instead
+// of one after the other with the rest of the GPU idle: workgroup 0 is tile_finish_kernel; workgroup 1 scans
+// the tile sums of the depth-ordered blocks of 256 Gaussians into instance offsets (scan_blocks_kernel) and
+// from them writes, for every chunk of EMIT_CHUNK instances, the block its first instance falls in and that
+// block's offset (the emission's chunk table).
+static_assert(TF_THREADS == SCAN_THREADS, "one launch, one workgroup size");
+__global__ void __launch_bounds__(TF_THREADS) tile_finish_offsets_kernel(
+    int gx, int gy, const int* __restrict__ diff, uint2* __restrict__ ranges, uint32_t* __restrict__ ghist, int passes,
+    int nbits, int lowbits, int nseg, uint32_t* __restrict__ seg_start, uint32_t* __restrict__ seg_tile0,
+    uint32_t* order_sums, int nb256, uint64_t* total, uint2* __restrict__ chunk_first, uint32_t chunks) {
+    if (blockIdx.x == 0) {
+        tile_finish_body(gx, gy, diff, ranges, ghist, passes, nbits, lowbits, nseg, seg_start, seg_tile0);
+        return;
+    }
+    scan_blocks_one(order_sums, true, nb256, total, nullptr);
+    __syncthreads();   // the offsets are this workgroup's own stores
+    for (int b = threadIdx.x; b < nb256; b += TF_THREADS) {
+        const uint32_t s0 = order_sums[b], s1 = order_sums[b + 1];
+        for (uint32_t c = (s0 + EMIT_CHUNK - 1) / EMIT_CHUNK; (uint64_t)c * EMIT_CHUNK < s1; ++c)
+            chunk_first[c] = make_uint2((uint32_t)b, s0);
+        if (b == nb256 - 1) chunk_first[chunks] = make_uint2((uint32_t)b, s0);  // "the chunk after the last" starts in the last block
+    }
+}
+
+hipError_t launch_tile_count(const GeomBuf& g, int P, int W, int H, const ImageView& im, hipStream_t st) {
+    const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
+    const size_t nd = (size_t)(gx + 1) * (gy + 1);
+    hipError_t e = hipMemsetAsync(im.tile_diff, 0, nd * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    const size_t lds_c = nd * sizeof(int);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_c);
+    if (e != hipSuccess) return e;
+    const int blocks = min(TC_BLOCKS, (P + TC_THREADS - 1) / TC_THREADS);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(blocks), dim3(TC_THREADS), lds_c, st, P, g.rect, gx, gy, im.tile_diff);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_finish_offsets(const GeomBuf& g, int n_visible, int W, int H, const ImageView& im, uint32_t* ghist,
+                                      int passes, int nbits, int lowbits, uint32_t* seg_start, uint32_t* seg_tile0,
+                                      uint2* chunk_first, uint32_t chunks, hipStream_t st) {
+    const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
+    const size_t lds_f = tile_finish_lds(gx, gy, passes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_finish_offsets_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+    if (e != hipSuccess) return e;
+    const int nb256 = (n_visible + PRE_BLOCK - 1) / PRE_BLOCK;
+    hipLaunchKernelGGL(tile_finish_offsets_kernel, dim3(2), dim3(TF_THREADS), lds_f, st, gx, gy, im.tile_diff, im.ranges,
+                       ghist, passes, nbits, lowbits, 1 << (nbits - lowbits), seg_start, seg_tile0, g.order_sums, nb256,
+                       g.total, chunk_first, chunks);
+    return hipGetLastError();
 }
 
 hipError_t launch_tile_ranges_from_rects(const GeomBuf& g, int P, int W, int H, const ImageView& im, uint32_t* ghist,

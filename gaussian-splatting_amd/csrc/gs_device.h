@@ -434,6 +434,7 @@ inline ImageView image_view(void* base, size_t W, size_t H) {
 #endif
 constexpr int SORT_TILE = GS_SORT_TILE;   // keys per onesweep workgroup
 constexpr int SORT_MAX_PASSES = 8;
+constexpr int EMIT_CHUNK = 4096;          // instances per workgroup of the key emission that partitions
 constexpr int SORT_BATCH_MAX = 8;         // independent sorts that share the launches of launch_radix_sort_u32_batch
 // Depth keys: the f32 bits of a view-space depth above the near plane (0.2, auxiliary.h:154-168: a point
 // with depth <= 0.2 is culled) minus the bits of 0.2 stay below 2^27 while the depth is below 0.2 * 2^16

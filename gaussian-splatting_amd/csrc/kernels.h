@@ -151,8 +151,10 @@ hipError_t fused_sort_prepare(void* temp, int64_t R, int n_visible, int nbits, h
 // kernels an instance is ONE word, (low digit << (32 - digit bits)) | Gaussian index, in keys[1]; the
 // segmented pass writes the Gaussian indices to vals[0] and nothing else (vals[1] and keys[0] stay unused).
 bool fused_sort_packs(int P, int nbits);
+// offsets_ready: launch_tile_finish_offsets has turned g.order_sums into offsets and written the chunk table
+// (otherwise the call does both itself, in two one-workgroup launches).
 hipError_t launch_emit_partition(const GeomBuf& g, int n_visible, int grid_x, int nbits, int64_t R, uint32_t* keys[2],
-                                 uint32_t* vals[2], void* temp, hipStream_t st, bool packed);
+                                 uint32_t* vals[2], void* temp, hipStream_t st, bool packed, bool offsets_ready);
 hipError_t launch_segmented_pass(int n_visible, int ntiles, int nbits, int64_t R, const uint2* ranges, uint32_t* keys[2],
                                  uint32_t* vals[2], void* temp, hipStream_t st, bool packed);
 // The same with 32-bit keys.  hist_ready: the digit histograms in the temp area were filled by the caller.
@@ -193,6 +195,16 @@ hipError_t launch_split_children(int64_t K, int n, const uint32_t* parents, cons
 // counts: host array of n device pointers to [N] ints (4-byte aligned rows start 16-byte aligned); mask [N] bytes, 4-byte aligned
 hipError_t launch_mark_nonzero(int64_t N, int n, const int* const* counts, uint8_t* mask, hipStream_t st);
 hipError_t launch_scan_u32(uint32_t* sums, int nb, uint64_t* total, hipStream_t st);
+// launch_tile_ranges_from_rects in two halves for the fused sort: the corner counts first; then, behind the
+// ordered rectangle gather, one launch of two workgroups: the tile ranges / histograms / segment tables, and
+// beside them the instance offsets of the depth-ordered blocks (in place in g.order_sums) with the emission's
+// chunk table (fused_chunk_table).
+hipError_t launch_tile_count(const GeomBuf& g, int P, int W, int H, const ImageView& im, hipStream_t st);
+hipError_t launch_tile_finish_offsets(const GeomBuf& g, int n_visible, int W, int H, const ImageView& im, uint32_t* ghist,
+                                      int passes, int nbits, int lowbits, uint32_t* seg_start, uint32_t* seg_tile0,
+                                      uint2* chunk_first, uint32_t chunks, hipStream_t st);
+// Where the emission's chunk table lives in the fused sort's temp area, and how many chunks there are.
+void fused_chunk_table(void* temp, int64_t R, int n_visible, int nbits, uint2** chunk_first, uint32_t* chunks);
 size_t compact_temp_bytes(int64_t N);
 hipError_t launch_compact_map(int64_t N, const uint8_t* keep, uint32_t* src_of_dst, void* temp, hipStream_t st,
                               uint64_t** total_dev);

@@ -480,6 +480,7 @@ constexpr int EP_THREADS = GS_EP_THREADS;
 #endif
 constexpr int EP_ITEMS = GS_EP_ITEMS;
 constexpr int EP_CHUNK = EP_THREADS * EP_ITEMS;  // instances per chunk
+static_assert(EP_CHUNK == EMIT_CHUNK, "the chunk table is also written by tile_finish_offsets_kernel");
 constexpr int EP_MAX_BLOCKS = EP_CHUNK / 256 + 1;
 constexpr int EP_MAX_PER = (EP_MAX_BLOCKS * 256 + EP_THREADS - 1) / EP_THREADS;
 static_assert(EP_CHUNK >= 2048, "fused_sort_temp_bytes sizes the chunk tables for chunks of at least 2048");
@@ -935,19 +936,26 @@ bool fused_sort_packs(int P, int nbits) {
     return (int64_t)P <= ((int64_t)1 << (32 - lowbits));
 }
 
+void fused_chunk_table(void* temp, int64_t R, int n_visible, int nbits, uint2** chunk_first, uint32_t* chunks) {
+    *chunk_first = reinterpret_cast<uint2*>(fused_temp_view(temp, R, n_visible, nbits).chunk_first);
+    *chunks = (uint32_t)((R + EP_CHUNK - 1) / EP_CHUNK);
+}
+
 hipError_t launch_emit_partition(const GeomBuf& g, int n_visible, int grid_x, int nbits, int64_t R, uint32_t* keys[2],
-                                 uint32_t* vals[2], void* temp, hipStream_t st, bool packed) {
+                                 uint32_t* vals[2], void* temp, hipStream_t st, bool packed, bool offsets_ready) {
     const FusedTemp f = fused_temp_view(temp, R, n_visible, nbits);
     int lowshift, lowbits;
     digit_of_pass(nbits, 2, 0, &lowshift, &lowbits);
     const int hb = nbits - lowbits;
     const int nb256 = (n_visible + PRE_BLOCK - 1) / PRE_BLOCK;
     const unsigned chunks = (unsigned)((R + EP_CHUNK - 1) / EP_CHUNK);
-    // instance offsets per block of 256 Gaussians (g.total was read by the host already; the scan rewrites the same values)
-    hipError_t e0 = launch_scan_u32(g.order_sums, nb256, g.total, st);
-    if (e0 != hipSuccess) return e0;
-    hipLaunchKernelGGL(chunk_map_kernel, dim3((nb256 + 255) / 256), dim3(256), 0, st, nb256, g.order_sums,
-                       reinterpret_cast<uint2*>(f.chunk_first), chunks);
+    if (!offsets_ready) {
+        // instance offsets per block of 256 Gaussians (g.total was read by the host already; the scan rewrites the same values)
+        hipError_t e0 = launch_scan_u32(g.order_sums, nb256, g.total, st);
+        if (e0 != hipSuccess) return e0;
+        hipLaunchKernelGGL(chunk_map_kernel, dim3((nb256 + 255) / 256), dim3(256), 0, st, nb256, g.order_sums,
+                           reinterpret_cast<uint2*>(f.chunk_first), chunks);
+    }
     EmitPartArgs a;
     a.sbin = g.sbin;
     a.offs = g.order_sums;
