@@ -349,10 +349,24 @@ def launch_ranks(n):
     if ndev < n and "GSPLAT_BENCH_BACKEND" not in env:
         log(f"launcher: {ndev} GPU(s) for {n} ranks: the ranks share devices and exchange through gloo (rehearsal)")
         env["GSPLAT_BENCH_BACKEND"] = "gloo"
-    procs = []
+    # Only the result line may reach this process's stdout: what else the ranks or their libraries print
+    # there (gloo announces its connections on stdout) goes to stderr.
+    import threading
+
+    def forward(stream):
+        for line in stream:
+            out = sys.stdout if line.startswith('{"metric"') else sys.stderr
+            out.write(line)
+            out.flush()
+
+    procs, readers = [], []
     for r in range(n):
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r))))
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                             env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, text=True)
+        t = threading.Thread(target=forward, args=(p.stdout,), daemon=True)
+        t.start()
+        procs.append(p)
+        readers.append(t)
     worst = 0
     alive = list(procs)
     while alive:
@@ -367,6 +381,8 @@ def launch_ranks(n):
                 log(f"launcher: a rank exited with code {rc}; ending the others")
                 for q in alive:
                     q.terminate()
+    for t in readers:
+        t.join(timeout=10.0)
     return worst
 
 
