@@ -153,6 +153,10 @@ class KernelTimer:
         return out
 
 
+def deferred_flag(use_params, sink, args):
+    return bool(use_params and sink is not None and sink.defer and not args.fwd_only)
+
+
 def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1, walked=None, from_rects=True, reached=None,
                       reached_any=None, packed=False):
     """Bytes one launch must move at least: per-unit figures times the units one
@@ -170,7 +174,8 @@ def algorithmic_bytes(kernel, P, visible, R, HW, passes, V=1, walked=None, from_
     return {
         "preprocess": 315.0 * visible + 20.0 * (P - visible),
         "depth_order": P * (16.0 + 8.0 + 4.0 + 4 * 16.0),       # bin read, pair write, histogram read, 4 passes
-        "depth_order_batch": V * P * (16.0 + 8.0 + 4.0 + 4 * 16.0),   # the same for the V views of a step in shared launches
+        # the same for the V views of a step in shared launches, on 27-bit keys: three passes
+        "depth_order_batch": V * P * (16.0 + 8.0 + 4.0 + 3 * 16.0),
         # gather + sbin write + sbin read; an instance leaves as one word (low tile digit | Gaussian index)
         # when the indices fit below the digit, else as a (tile id, index) pair
         "emit_keys": P * (4.0 + 16.0 + 16.0 + 16.0) + (4.0 if packed else 8.0) * R,
@@ -425,6 +430,9 @@ def main():
                          "Gaussians some view of the step (any rank) reached; auto: sparse while those are at most "
                          "35 %% of the rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timeline", action="store_true",
+                    help="print (stderr) when each stage of each view of the last timed step began and ended on the GPU, "
+                         "in ms from the start of that step: how the views on their streams overlap")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-view / reference-API / FPS measurements")
     ap.add_argument("--fwd-only", action="store_true", help="time rendering only (render FPS)")
     args = ap.parse_args()
@@ -579,6 +587,21 @@ def main():
     log(f"[rank {rank}] host launch time per step (ms): " +
         " ".join(f"{(b - a) * 1e3:.1f}" for a, b in zip([t0] + marks[:-1], marks)))
     timer.arm(None)
+    if args.timeline and rank == 0:
+        k = args.steps - 1
+        rows = timer.events[k * V:(k + 1) * V]
+        origin = rows[0][16] if batch_fwd else rows[0][0]
+        at = lambda row, slot: origin.elapsed_time(row[slot])
+        if batch_fwd:
+            log("timeline (ms): batched preprocess %.2f-%.2f, batched depth order %.2f-%.2f" %
+                (at(rows[0], 16), at(rows[0], 17), at(rows[0], 19), at(rows[0], 20)))
+        for v, row in enumerate(rows):
+            lane = v % max(1, args.streams)
+            log("timeline view %d lane %d: binning %.2f-%.2f  render_fwd %.2f-%.2f  stats %.2f  | backward %.2f-%.2f "
+                "(render_bwd %.2f-%.2f)" % (v, lane, at(row, 3), at(row, 6), at(row, 7), at(row, 8), at(row, 9),
+                                            at(row, 10), at(row, 12), at(row, 11), at(row, 12)))
+        if deferred_flag(use_params, sink, args):
+            log("timeline: batched per-Gaussian backward %.2f-%.2f" % (at(rows[V - 1], 14), at(rows[V - 1], 15)))
     if world > 1:
         tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
